@@ -1,0 +1,27 @@
+"""Build the CPU oracle for one generated model plugin (TEST INFRASTRUCTURE).
+
+    python oracle/build_oracle.py <dir containing modelspec.h> [out.so]
+
+gcc -O2 -ffp-contract=off (no FMA contraction, no -ffast-math): SURVEY.md §8(d) "CPU baseline beside it".
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(spec_dir, out=None, opt='-O2'):
+    out = out or os.path.join(spec_dir, 'liboracle.so')
+    src = os.path.join(HERE, 'egdst_oracle.c')
+    spec = os.path.join(spec_dir, 'modelspec.h')
+    if (os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(spec))):
+        return out
+    cmd = ['gcc', opt, '-ffp-contract=off', '-std=gnu99', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
+           '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-I', spec_dir, src, '-o', out, '-lm']
+    subprocess.run(cmd, check=True)
+    return out
+
+
+if __name__ == '__main__':
+    print(build(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None))
