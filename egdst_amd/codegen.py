@@ -201,6 +201,7 @@ def generate_modelspec(model):
     w('#ifndef MS_FN')
     w('#error "define MS_FN (function qualifier) and MS_TABLE (constant-table qualifier) before including modelspec.h"')
     w('#endif')
+    w('#define MS_LABEL "%s"' % re.sub(r'[^A-Za-z0-9 _.-]', '', m.label))
     w('#define MS_NNST %d' % m.nnst)
     w('#define MS_NND %d' % m.nnd)
     w('#define MS_NST %d' % m.nst)

@@ -1,0 +1,225 @@
+// egdst_device.h -- device-side numerics of the EGM step for gfx950 (wave64).
+//
+// Everything here is fp64 and follows the arithmetic of the reference expression by expression
+// (two divisions per interpolation etc.), so that results stay within 1e-10 relative of the CPU
+// path; this translation unit is built with -ffp-contract=off (no FMA contraction) because a
+// contracted a*b+c can flip discrete decisions at ties in the envelopes.
+//
+// Reference lines implemented by each function are cited inline as file:line of
+// /root/reference/@egdstmodel/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define MS_FN static __device__ __forceinline__
+#define MS_TABLE static __device__ const
+#include "modelspec.h"
+
+#define EG_TOL MS_TOLERANCE
+#define EG_ZEROC MS_ZEROCONSUMPTION
+#define EG_DPD MS_DOUBLEPOINT_DELTA
+#define EG_A0T 0.0  // egdst_solver.c:49
+
+// ---- problem geometry shared by all kernels -------------------------------------------------
+struct Geom {
+    int t0, T, nt, ngridm, ngridmax, nthrhmax, ny, ndraw, nslots, S;  // S = ngridmax+1 (row stride of a table)
+    double mmax, a0;
+};
+
+// Device-resident state of a batch (all pointers are device memory).
+struct Batch {
+    Geom g;
+    const double *par;   // [ndraw][MS_NPARAM]
+    const double *qw;    // [ny] weights
+    const double *qz;    // [ny] standard-normal nodes (Acklam of the GL abscissae, egdst_solver.c:164)
+    // period tables: index ((slot*ndraw+draw)*MS_NST+ist)
+    double *tM, *tC, *tV;   // * S
+    double *tD, *tTH;       // * nthrhmax
+    int *tlen, *tthlen;     // rows incl. the a0 row (0 = unsolved), thresholds
+    // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*ngridmax + n); n=0 is the probe's point
+    double *cM, *cC, *cV, *cR;  // M, C, V, and the M returned to the guess generator
+    int *cSt, *cCnt;            // status (0 normal, 1 c1<=0, 2 evf=-inf), evaluations done for the point
+    struct ProbeOut *probe;     // [(draw*MS_NST+ist)*MS_ND+id]
+    // envelope workspaces per (draw,ist): W = (MS_ND+1)*ngridmax entries
+    double *pM, *pC, *pV;  int *pF;    // per-choice lists, consecutive (the reference's mgridvecs)
+    double *sM, *sC, *sV;  int *sF;    // secondary-envelope input (pieces with their extrapolation points)
+    double *qM, *qC, *qV;  int *qF;    // points sorted in comp1 order
+    int *rank;                          // [W] sorted position of each input point
+    int *fstart, *fdims, *fcur, *fmark; // [ngridmax+MS_ND+2] per-function bookkeeping
+    double *eM, *eV, *eC;               // [ngridmax] output of a secondary envelope
+    double *eTH, *eIX;                  // [ngridmax]
+    int *stack;                         // [2*ngridmax] pending crossings
+    // status
+    int *status;          // [ndraw] first error code
+    int *where;           // [2*ndraw] (it, ist) of that error
+    unsigned long long *evals;  // [ndraw]
+    int *dbg;             // [16*ndraw] diagnostics of a tripped internal guard
+};
+
+struct ProbeOut {
+    int active;       // choice is in the choice set (and the state feasible)
+    int np;           // 1 if the probe stored a kept point at candidate index 0
+    int grid;         // 1 if the guess generator entered the grid stage (points n>=1 may be requested)
+    int ncalls;       // calls made before the first grid point (for the runaway guard, egdst_solver.c:963)
+    int ntogenerate;
+    int probe_evals;
+    double lim1, lim2, lim3, lim3p, k3;   // egdst_solver.c:1051-1099
+    double A0;        // last guess before the grid stage
+    double M0;        // M returned for it
+    double evfa0;     // egdst_solver.c:430,593,643
+};
+
+// ---- inverse normal cdf (Acklam), egdst_lib.c:435-519 ---------------------------------------
+__host__ __device__ inline double eg_inv_normal_cdf(double p)
+{
+    const double a0c = -3.969683028665376e+01, a1c = 2.209460984245205e+02, a2c = -2.759285104469687e+02,
+                 a3c = 1.383577518672690e+02, a4c = -3.066479806614716e+01, a5c = 2.506628277459239e+00;
+    const double b0c = -5.447609879822406e+01, b1c = 1.615858368580409e+02, b2c = -1.556989798598866e+02,
+                 b3c = 6.680131188771972e+01, b4c = -1.328068155288572e+01;
+    const double c0c = -7.784894002430293e-03, c1c = -3.223964580411365e-01, c2c = -2.400758277161838e+00,
+                 c3c = -2.549732539343734e+00, c4c = 4.374664141464968e+00, c5c = 2.938163982698783e+00;
+    const double d0c = 7.784695709041462e-03, d1c = 3.224671290700398e-01, d2c = 2.445134137142996e+00,
+                 d3c = 3.754408661907416e+00;
+    if (p < 0 || p > 1) return 0.0;
+    if (p == 0) return -HUGE_VAL;
+    if (p == 1) return HUGE_VAL;
+    if (p < 0.02425) {
+        double q = sqrt(-2 * log(p));
+        return (((((c0c * q + c1c) * q + c2c) * q + c3c) * q + c4c) * q + c5c) /
+               ((((d0c * q + d1c) * q + d2c) * q + d3c) * q + 1);
+    }
+    if (p > 0.97575) {
+        double q = sqrt(-2 * log(1 - p));
+        return -(((((c0c * q + c1c) * q + c2c) * q + c3c) * q + c4c) * q + c5c) /
+               ((((d0c * q + d1c) * q + d2c) * q + d3c) * q + 1);
+    }
+    double q = p - 0.5, r = q * q;
+    return (((((a0c * r + a1c) * r + a2c) * r + a3c) * r + a4c) * r + a5c) * q /
+           (((((b0c * r + b1c) * r + b2c) * r + b3c) * r + b4c) * r + 1);
+}
+
+// ---- shocks (egdst_lib.c:66-100) -------------------------------------------------------------
+MS_FN double eg_shock_node(const ms_env *E, const ms_pv *cur, const ms_pv *nxt, double z)
+{
+#if MS_DISTRIB == 1
+    return exp(ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt));
+#else
+    return ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt);
+#endif
+}
+MS_FN double eg_shock_mean(const ms_env *E, const ms_pv *cur, const ms_pv *nxt)
+{
+#if MS_DISTRIB == 1
+    return exp(ms_mu(E, cur, nxt) + ms_sigma(E, cur, nxt) * ms_sigma(E, cur, nxt) / 2);
+#else
+    return ms_mu(E, cur, nxt);
+#endif
+}
+MS_FN double eg_shock_uniform(double u, double mu, double sigma)
+{
+#if MS_DISTRIB == 1
+    return exp(sigma * eg_inv_normal_cdf(u) + mu);
+#else
+    return sigma * eg_inv_normal_cdf(u) + mu;
+#endif
+}
+
+// ---- bracket search + interpolation (egdst_lib.c:123-206) -----------------------------------
+// kind 0: bracket for interpolation/extrapolation; kind 1: last threshold <= x.
+static __device__ __forceinline__ int eg_bracket(double x, const double *__restrict__ g, int n, int kind)
+{
+    if (x < g[1]) return 0;
+    if (kind == 0 && x >= g[n - 2]) return n - 2;
+    if (kind == 1 && x >= g[n - 1]) return n - 1;
+    int lo = 1, hi = n - 2;
+    const bool asc = g[0] <= g[n - 1];
+    while (hi - lo > 1) {
+        int mid = (hi + lo) / 2;
+        if (asc && g[mid] > x)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    return lo;
+}
+
+static __device__ __forceinline__ double eg_lerp(double x, double g0, double g1, double f0, double f1)
+{
+    return f1 * (x - g0) / (g1 - g0) + f0 * (g1 - x) / (g1 - g0);
+}
+
+// One next-period table (state ist1 of period it+1), row 0 = (a0, 0, evf(a0)).
+struct Tab {
+    const double *M, *C, *V, *TH, *D;
+    int len, thlen;  // rows incl. the a0 row; thresholds
+};
+
+static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw, int ist)
+{
+    size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    Tab t;
+    t.M = b.tM + k * b.g.S;
+    t.C = b.tC + k * b.g.S;
+    t.V = b.tV + k * b.g.S;
+    t.TH = b.tTH + k * b.g.nthrhmax;
+    t.D = b.tD + k * b.g.nthrhmax;
+    t.len = b.tlen[k];
+    t.thlen = b.tthlen[k];
+    return t;
+}
+
+// Next-period value at nxt->cash (valuefunc, egdst_solver.c:755-772 with linter_extrap, egdst_lib.c:179-206).
+static __device__ __forceinline__ double eg_next_value(const ms_env *E, const Tab &t, const ms_pv *nxt)
+{
+    const double evf1 = t.V[0], a0 = E->a0, x = nxt->cash;
+    if (x < t.M[1] && evf1 > -INFINITY) return ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
+    const double *g = t.M + 1, *f = t.V + 1;
+    const int n = t.len - 1;
+    int i = eg_bracket(x, g, n, 0);
+    double f0 = f[i], f1 = f[i + 1];
+    if (!isfinite(f0)) return f0;
+    if (!isfinite(f1)) return f1;
+    double g0 = g[i], g1 = g[i + 1];
+    if (x > a0 && (x > g[n - 1] || x < g[0])) {
+        double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
+        return f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
+    }
+    return eg_lerp(x, g0, g1, f0, f1);
+}
+
+// One (next state, shock node) term of the expectation: the body at egdst_solver.c:548-570.
+// Returns c1; on c1>0 fills the two weighted terms.  nxt->ist/shock must be set; fills nxt->cash, nxt->id.
+static __device__ __forceinline__ double eg_term(const ms_env *E, const Tab &t, const ms_pv *cur, ms_pv *nxt,
+                                                 double pr1, int keep, double *t_rhs, double *t_evf)
+{
+    nxt->cash = ms_cashinhand(E, cur, nxt);
+    const int n1 = t.len;
+    int i = eg_bracket(nxt->cash, t.M, n1, 0);
+    double c1 = eg_lerp(nxt->cash, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
+    if (nxt->cash > t.M[n1 - 1]) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
+    *t_rhs = 0;
+    *t_evf = 0;
+    if (c1 <= 0) return c1;
+    if (!MS_OPTIM_MUNOD || (!MS_OPTIM_UNOD && keep == 1 && nxt->cash < t.M[1]))
+        nxt->id = (int)t.D[eg_bracket(nxt->cash, t.TH, t.thlen, 1)];  // optimd, egdst_lib.c:129-132
+    else
+        nxt->id = 0;
+    *t_rhs = pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
+    if (keep == 1) *t_evf = pr1 * eg_next_value(E, t, nxt);
+    return c1;
+}
+
+// Newton inversion of the budget (cashinhandinverse, egdst_lib.c:275-296); *err set on failure.
+static __device__ __forceinline__ double eg_invert_budget(const ms_env *E, ms_pv cur, ms_pv nxt, double target, int *err)
+{
+    int cnt = 0;
+    nxt.savings = target;
+    while (fabs(ms_cashinhand(E, &cur, &nxt) - target) > EG_ZEROC / 10) {
+        nxt.savings -= (ms_cashinhand(E, &cur, &nxt) - target) / ms_cashinhand_marginal(E, &cur, &nxt);
+        if (++cnt >= 100) {
+            *err = 24;
+            return -1.0;
+        }
+    }
+    return nxt.savings;
+}

@@ -1,0 +1,381 @@
+// egdst_envelope.h -- upper envelopes of tabulated value functions on the device.
+//
+// Restates envelop/funcvalue/linter2/thresholds/brsolve (egdst_solver.c:1165-1968) over SoA arrays:
+// the points are already sorted by (M asc, V desc, function asc) (comp1, :1570-1582) by the
+// rank-merge of the calling kernel; `rank[fstart[f]+k]` is the sorted position of the k-th point
+// of function f.  The walk itself is data-dependent and sequential (one lane); the recursion of
+// thresholds() is unrolled onto an explicit stack of pending (previous, entering) function pairs.
+#pragma once
+#include "egdst_device.h"
+
+struct EnvCtx {
+    const ms_env *E;
+    int it, ist, nf;
+    const double *m, *c, *v;  // sorted points
+    const int *f;
+    const int *rank, *fstart;
+    int *dims, *cur, *mark, *stack;
+    int stackcap;
+    // expected value at a0 per function: primary -> evfa0[f]; secondary -> (f==sec_id ? sec_ev : -inf)
+    const double *evfa0;
+    int sec_id;
+    double sec_ev;
+    double *og, *ov, *oc, *oth, *oix;
+    int oi, oj, ngridmax, nthrhmax;
+    int cap, npts;  // capacity of rank[] and number of sorted points (bounds guard)
+    int *dbg;       // [16] diagnostics of a tripped guard
+    int err;
+};
+
+static __device__ __forceinline__ double env_evf(const EnvCtx &e, int f)
+{
+    if (e.sec_id >= 0) return f == e.sec_id ? e.sec_ev : -INFINITY;
+    return e.evfa0[f];
+}
+static __device__ __forceinline__ int env_at(EnvCtx &e, int f, int k)
+{
+    const int o = e.fstart[f] + k;
+    if (o < 0 || o >= e.cap) {  // never expected; turns a wild access into an error code
+        if (!e.err && e.dbg && atomicCAS(&e.dbg[0], 0, 2701) == 0) {
+            int n0 = 0, n1 = 0;
+            for (int q = 0; q < e.npts; q++) n0 += (e.f[q] == 0), n1 += (e.f[q] == 1);
+            e.dbg[1] = f, e.dbg[2] = k, e.dbg[3] = e.ist, e.dbg[4] = e.it, e.dbg[5] = e.nf;
+            e.dbg[6] = e.npts, e.dbg[7] = e.sec_id, e.dbg[8] = e.oi, e.dbg[9] = e.oj;
+            e.dbg[10] = e.fstart[0], e.dbg[11] = e.fstart[1], e.dbg[12] = e.dims[0], e.dbg[13] = e.dims[1];
+            e.dbg[14] = n0, e.dbg[15] = n1;
+        }
+        e.err = 2701;
+        return 0;
+    }
+    const int r = e.rank[o];
+    if (r < 0 || r >= e.npts) {
+        e.err = 2702;
+        return 0;
+    }
+    return r;
+}
+
+// value (which=0) or consumption (which=1) of f on the segment that starts at its k-th point; -inf outside
+// the segment: "No extrapolation allowed: this is essential for the correct envelop" (linter2, :1585-1593)
+static __device__ __forceinline__ double env_seg(EnvCtx &e, int f, int k, double x, int which)
+{
+    int a = env_at(e, f, k), b = env_at(e, f, k + 1);
+    double ga = e.m[a], gb = e.m[b];
+    double fa = which ? e.c[a] : e.v[a], fb = which ? e.c[b] : e.v[b];
+    if (x == ga) return fa;
+    if (x < ga) return -INFINITY;
+    if (x > gb) return -INFINITY;
+    return fb * (x - ga) / (gb - ga) + fa * (gb - x) / (gb - ga);
+}
+
+static __device__ __forceinline__ double env_analytic(const EnvCtx &e, int f, double x)
+{
+    ms_pv cv;
+    cv.it = e.it;
+    cv.ist = e.ist;
+    cv.id = f;
+    cv.cash = cv.savings = cv.shock = 0;
+    return ms_utility(e.E, &cv, x - e.E->a0) + ms_discount(e.E, &cv) * env_evf(e, f);
+}
+
+static __device__ __forceinline__ double env_fn(EnvCtx &e, int f, double x)  // funcvalue, :1553-1567
+{
+    if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 0);
+    if (env_evf(e, f) == -INFINITY) return -INFINITY;
+    return env_analytic(e, f, x);
+}
+
+static __device__ __forceinline__ double env_policy(EnvCtx &e, int f, double x)  // :1406-1408, :1859-1864
+{
+    if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 1);
+    if (env_evf(e, f) == -INFINITY) return EG_ZEROC;
+    return x - e.E->a0;
+}
+
+static __device__ __forceinline__ double env_sgn(double x) { return x > 0 ? 1.0 : -1.0; }
+
+// brsolve (:1918-1968): bisection between an analytic value function `fa` and the segment (fl,kl)
+static __device__ __forceinline__ void env_bisect(EnvCtx &e, double *b0, double *b1, int fl, int kl, int fa)
+{
+    for (;;) {
+        double f0 = env_analytic(e, fa, *b0), f1 = env_analytic(e, fa, *b1);
+        double s0 = env_sgn(f0 - env_seg(e, fl, kl, *b0, 0)), s1 = env_sgn(f1 - env_seg(e, fl, kl, *b1, 0));
+        if (s0 == s1) {
+            e.err = 22;
+            return;
+        }
+        if (*b0 > *b1) {
+            e.err = 23;
+            return;
+        }
+        if (fabs(*b0 - *b1) < 2 * EG_DPD || fabs(f0 - f1) < EG_DPD) {
+            *b0 = (*b0 + *b1) / 2;
+            return;
+        }
+        double mid = (*b0 + *b1) / 2;
+        double sm = env_sgn(env_analytic(e, fa, mid) - env_seg(e, fl, kl, mid, 0));
+        if (s0 == sm)
+            *b0 = mid;
+        else if (s1 == sm)
+            *b1 = mid;
+        else
+            return;
+    }
+}
+
+// thresholds (:1596-1915)
+static __device__ __forceinline__ void env_crossing(EnvCtx &e, int pri0, int nwi0, int mode)
+{
+    const double a0 = e.E->a0;
+    int sp = 0;
+    e.stack[0] = pri0;
+    e.stack[1] = nwi0;
+    sp = 1;
+    while (sp > 0 && !e.err) {
+        sp--;
+        const int pri = e.stack[2 * sp], nwi = e.stack[2 * sp + 1];
+        e.mark[pri] = 1;
+        e.mark[nwi] = 1;
+        const int cp = e.cur[pri], cn = e.cur[nwi];
+        double x = 0, top = 0;
+        if (cp == -1 && cn != -1) {
+            if (env_evf(e, pri) == -INFINITY)
+                x = e.m[env_at(e, pri, 0)];
+            else {
+                double br0 = e.m[env_at(e, nwi, cn)];
+                double br1 = MS_MIN(e.m[env_at(e, pri, 0)], e.m[env_at(e, nwi, cn + 1)]);
+                env_bisect(e, &br0, &br1, nwi, cn, pri);
+                if (e.err) return;
+                x = br0;
+            }
+            top = env_seg(e, nwi, cn, x, 0);
+        } else if (cp != -1 && cn == -1) {
+            if (env_evf(e, nwi) == -INFINITY)
+                x = e.m[env_at(e, nwi, 0)];
+            else {
+                double br0 = e.m[env_at(e, pri, cp)];
+                double br1 = MS_MIN(e.m[env_at(e, nwi, 0)], e.m[env_at(e, pri, cp + 1)]);
+                env_bisect(e, &br0, &br1, pri, cp, nwi);
+                if (e.err) return;
+                x = br0;
+            }
+            top = env_seg(e, pri, cp, x, 0);
+        } else if (cp == -1 && cn == -1) {
+            e.err = 21;
+            return;
+        } else {
+            const int ip0 = env_at(e, pri, cp), ip1 = env_at(e, pri, cp + 1);
+            const int in0 = env_at(e, nwi, cn), in1 = env_at(e, nwi, cn + 1);
+            const double p0m = e.m[ip0], p1m = e.m[ip1], p0v = e.v[ip0], p1v = e.v[ip1];
+            const double n0m = e.m[in0], n1m = e.m[in1], n0v = e.v[in0], n1v = e.v[in1];
+            const double icn = (n0v * n1m - n1v * n0m) / (n1m - n0m);  // intercepts
+            const double icp = (p0v * p1m - p1v * p0m) / (p1m - p0m);
+            if (p1m == p0m) {  // previous max is vertical
+                x = p0m;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else if (n1m == n0m) {  // entering function is vertical
+                x = n0m;
+                top = (x * (p1v - p0v) / (p1m - p0m)) + icp;
+            } else if (((n1v - n0v) / (n1m - n0m)) == ((p1v - p0v) / (p1m - p0m))) {  // identical slopes
+                x = (p0m + p1m + n0m + n1m) / 4;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else {
+                x = (icp - icn) / (((n1v - n0v) / (n1m - n0m)) - ((p1v - p0v) / (p1m - p0m)));
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            }
+        }
+        int best = -1;
+        for (int k = 0; k < e.nf; k++) {
+            if (e.mark[k] == 1) continue;
+            // u(.)+beta*(-inf) is -inf; skipping the call keeps segment indices out of the model's id tables
+            double t = (e.cur[k] >= 0) ? env_seg(e, k, e.cur[k], x, 0)
+                                       : (env_evf(e, k) == -INFINITY ? -INFINITY : env_analytic(e, k, x));
+            if (top < t) {
+                top = t;
+                best = k;
+                if (mode == 0) break;
+            }
+        }
+        if (best != -1) {  // a third function is higher at the crossing: split (:1827-1845)
+            if (2 * (sp + 2) > e.stackcap) {
+                e.err = 2703;
+                return;
+            }
+            if (mode != 0) {
+                e.stack[2 * sp] = best;
+                e.stack[2 * sp + 1] = nwi;
+                sp++;
+            }
+            e.stack[2 * sp] = pri;
+            e.stack[2 * sp + 1] = best;
+            sp++;
+            continue;
+        }
+        const double pol0 = env_policy(e, pri, x), pol1 = env_policy(e, nwi, x);
+        e.og[e.oi] = x;
+        e.ov[e.oi] = top;
+        e.oc[e.oi] = (pol0 + pol1) / 2;
+        e.oth[e.oj] = x;
+        e.oix[e.oj] = nwi;
+        e.oi += 1;
+        e.oj += 1;
+        if (e.oi >= e.ngridmax) {
+            e.err = 13;
+            return;
+        }
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return;
+        }
+        if (env_evf(e, nwi) == -INFINITY && e.cur[nwi] == -1) {  // :1892-1900
+            e.oc[e.oi - 1] = pol0;
+            e.og[e.oi - 1] = e.og[e.oi - 1] - EG_TOL;
+        } else if (EG_DPD > 0) {  // double point at the kink, :1902-1913
+            e.oc[e.oi - 1] = pol0;
+            e.og[e.oi] = x + EG_DPD;
+            e.ov[e.oi] = top;
+            e.oc[e.oi] = pol1;
+            e.oi += 1;
+            if (e.oi >= e.ngridmax) {
+                e.err = 13;
+                return;
+            }
+        }
+    }
+}
+
+static __device__ __forceinline__ void env_reset_marks(EnvCtx &e)
+{
+    for (int l = 0; l < e.nf; l++) e.mark[l] = (e.dims[l] > 0 ? 0 : 1);
+}
+static __device__ __forceinline__ void env_push(EnvCtx &e, double g, double v, double c)
+{
+    e.og[e.oi] = g;
+    e.ov[e.oi] = v;
+    e.oc[e.oi] = c;
+    e.oi++;
+}
+
+// The merge walk (:1262-1550).  dims[] must hold the number of points per function, npts their sum.
+static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
+{
+    const double a0 = e.E->a0;
+    for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
+    double bound = INFINITY;  // min over functions of the last grid point (:1266-1271)
+    for (int f = 0; f < e.nf; f++)
+        if (e.dims[f] > 0) {
+            double last = e.m[env_at(e, f, e.dims[f] - 1)];
+            if (last < bound) bound = last;
+        }
+    e.oi = e.oj = 0;
+    int ci = 0;
+    for (int i = 0; i < npts && e.m[i] <= bound && !e.err; i++) {
+        const int f = e.f[i];
+        const double x = e.m[i];
+        if (f < 0 || f >= e.nf || e.dims[f] <= 0) {  // sorted stream inconsistent with the per-function lists
+            if (e.dbg && atomicCAS(&e.dbg[0], 0, 2708) == 0)
+                e.dbg[1] = f, e.dbg[2] = i, e.dbg[3] = e.npts, e.dbg[4] = e.nf, e.dbg[5] = e.sec_id, e.dbg[6] = e.ist;
+            e.err = 2708;
+            return;
+        }
+        if (e.oi > 0 && e.og[e.oi - 1] == x) {  // duplicate grid point (:1290-1298)
+            e.cur[f]++;
+            continue;
+        }
+        const int self = env_at(e, f, e.cur[f] + 1);
+        double fv = e.v[self];
+        if (e.oj == 0) {  // first point of the common grid (:1303-1347)
+            double t = fv;
+            ci = f;
+            for (int j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0 || j == f) continue;
+                fv = env_fn(e, j, x);
+                if (fv > t) t = fv, ci = j;
+                if (fv == t && ci > j) ci = j;
+            }
+            e.oth[e.oj] = a0;
+            e.oix[e.oj] = ci;
+            e.oj++;
+            if (e.oj >= e.nthrhmax) {
+                e.err = 20;
+                return;
+            }
+            if (ci == f) {
+                env_push(e, x, t, e.c[self]);
+                if (e.oi >= e.ngridmax) {
+                    e.err = 13;
+                    return;
+                }
+            }
+        } else if ((int)e.oix[e.oj - 1] == f) {  // point of the current max function (:1348-1416)
+            int above = 0, j;
+            double t;
+            for (j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0 || j == f) continue;
+                t = env_fn(e, j, x);
+                if (fv < t) {
+                    above = 1;
+                    if (x != bound) break;
+                    fv = t;
+                    ci = j;
+                }
+            }
+            if (!above) {
+                env_push(e, x, fv, e.c[self]);
+                if (e.oi == e.ngridmax) {
+                    e.err = 13;
+                    return;
+                }
+            } else if (x != bound) {
+                env_reset_marks(e);
+                env_crossing(e, f, j, 0);
+                if (e.err) return;
+            } else {
+                env_reset_marks(e);
+                env_crossing(e, f, ci, 1);
+                if (e.err) return;
+                e.og[e.oi] = x;
+                e.ov[e.oi] = env_fn(e, ci, x);
+                // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
+                e.oc[e.oi] = (e.cur[ci] >= 0) ? env_seg(e, ci, e.cur[ci], x, 1) : x - a0;
+                e.oi++;
+                if (e.oi >= e.ngridmax) {
+                    e.err = 13;
+                    return;
+                }
+            }
+        } else {  // point of another function (:1417-1516)
+            ci = (int)e.oix[e.oj - 1];
+            double t = env_fn(e, ci, x);
+            if (t < fv) {
+                int cj = -1;
+                for (int j = 0; j < e.nf; j++) {
+                    if (e.dims[j] <= 0 || j == f || j == ci) continue;
+                    t = env_fn(e, j, x);
+                    if ((fv < t) || (fv == t && j < cj)) fv = t, cj = j;
+                }
+                env_reset_marks(e);
+                if (cj == -1) {
+                    env_crossing(e, ci, f, 1);
+                    if (e.err) return;
+                    env_push(e, x, fv, e.c[self]);
+                    if (e.oi >= e.ngridmax) {
+                        e.err = 13;
+                        return;
+                    }
+                } else {
+                    env_crossing(e, ci, cj, 1);
+                    if (e.err) return;
+                    if (x == bound) {
+                        double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
+                        env_push(e, x, vv, pp);
+                    }
+                }
+            } else if (x == bound) {
+                double vv = env_fn(e, ci, x), pp = env_policy(e, ci, x);
+                env_push(e, x, vv, pp);
+            }
+        }
+        e.cur[f] = MS_MIN(e.cur[f] + 1, e.dims[f] - 2);
+    }
+}

@@ -1,0 +1,1030 @@
+// egdst_kernels.hip -- backward-induction DC-EGM solver and forward simulator for MI355X (gfx950).
+//
+// One backward period = four launches on one stream:
+//   k_probe     one wave per (draw, state, choice): the sequential head of the guess generator
+//               (adraw stage 0/1 and the zero-consumption resend, egdst_solver.c:955-1099) with
+//               each full expectation evaluated cooperatively by the 64 lanes (one lane per
+//               shock node) and accumulated in the reference's order;
+//   k_grid      one lane per remaining end-of-period asset point: closed-form log grid
+//               (egdst_solver.c:1110-1136) + the serial (next state, shock) loop of egmbellman
+//               (egdst_solver.c:494-574) + Euler inversion (:628-650);
+//   k_envelope  one workgroup per (draw, state): stop rule (:1100,1150), compaction, secondary
+//               envelope (:776-913), rank-merge sort + primary envelope (:1165-1550), saveoutput
+//               layout (:917-952);
+// the terminal period uses k_terminal (:433-476) + k_envelope.  k_simulate runs one lane per
+// simulated agent (egdst_simulator.c:204-383).  Parameter draws are independent: every kernel
+// is batched over `draw`, which is also the unit sharded across GPUs (no data-path collective).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+#include "egdst_device.h"
+#include "egdst_envelope.h"
+#include "../../include/egdst.h"
+
+#ifndef WAVE  // the sanitizer harness (tests/cpu_emu) overrides these with 1
+#define WAVE 64
+#define GRID_BS 256
+#define ENV_BS 256
+#endif
+
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void eg_fail(const Batch &b, int draw, int it, int ist, int code)
+{
+    if (atomicCAS(&b.status[draw], 0, code) == 0) {
+        b.where[2 * draw] = it;
+        b.where[2 * draw + 1] = ist;
+    }
+}
+
+static __device__ __forceinline__ ms_env eg_env(const Batch &b, int draw)
+{
+    ms_env E;
+    E.t0 = b.g.t0;
+    E.T = b.g.T;
+    E.ngridm = b.g.ngridm;
+    E.ngridmax = b.g.ngridmax;
+    E.nthrhmax = b.g.nthrhmax;
+    E.ny = b.g.ny;
+    E.mmax = b.g.mmax;
+    E.a0 = b.g.a0;
+    E.par = b.par + (size_t)draw * MS_NPARAM;
+    return E;
+}
+
+static __device__ __forceinline__ size_t eg_cand(const Batch &b, int draw, int ist, int id)
+{
+    return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.ngridmax;
+}
+
+// ---------------------------------------------------------------------------------------------
+// terminal period (egdst_solver.c:433-476, END2): M_i = trinv(m1 + i (m2-m1)/(ngridm-1)), C = M, V = u(C)
+__global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
+{
+    const int combo = blockIdx.y;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int i = blockIdx.x * GRID_BS + threadIdx.x;
+    if (b.status[draw]) return;
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = id;
+    cur.cash = cur.savings = cur.shock = 0;
+    ProbeOut *P = &b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    const int act = ms_feasible(&E, &cur) == 1 && ms_inchoiceset(&E, &cur) == 1;
+    if (i == 0) {
+        P->active = act;
+        P->np = 0;
+        P->grid = 0;
+        P->probe_evals = 0;
+        P->evfa0 = -INFINITY;
+    }
+    if (!act || i >= b.g.ngridm) return;
+    const double m1 = ms_tr(&E, &cur, EG_ZEROC - EG_A0T), m2 = ms_tr(&E, &cur, b.g.mmax - EG_A0T);
+    const double m = ms_trinv(&E, &cur, m1 + i * (m2 - m1) / (b.g.ngridm - 1)) + EG_A0T;
+    const double c = m - EG_A0T;
+    const size_t o = eg_cand(b, draw, ist, id) + i;
+    b.cM[o] = m;
+    b.cC[o] = c;
+    b.cV[o] = ms_utility(&E, &cur, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full expectation at one savings guess, evaluated by one wave: lane l handles shock node l of the
+// current next-state; the weighted terms are then accumulated in (ist1 asc, iy asc) order by every
+// lane redundantly, so that sums and early exits equal the serial loop (egdst_solver.c:494-574).
+// Returns 0 normal, 1 c1<=0, 2 evf=-inf, <0 hard error (-code).  brk_* describe the break point.
+static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
+                                          double savings, int keep, double *rhs_o, double *evf_o, int *nev,
+                                          int *brk_ist, double *brk_shock, double *brk_cash)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int ny = b.g.ny;
+    double rhs = 0, evf = 0, checksum = 0, c1_last = 1.0;
+    int status = 0, terr = 0, cnt = 0;
+    ms_pv nxt;
+    nxt.it = cur->it + 1;
+    nxt.id = 0;
+    nxt.cash = 0;
+    nxt.shock = 0;
+    nxt.savings = savings;
+    for (int ist1 = 0; ist1 < MS_NST && status == 0; ist1++) {
+        nxt.ist = ist1;
+        if (ms_feasible(E, &nxt) != 1) continue;
+        double pr1pre = 0;
+        if (MS_OPTIM_TRPRNOSH) {
+            pr1pre = ms_trpr(E, cur, &nxt, &terr);
+            if (terr) return -25;
+            if (pr1pre == 0.0) continue;
+        }
+        const int niy = (ms_sigma(E, cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
+        const Tab t = eg_tab(b, slot1, draw, ist1);
+        if (t.len < 2) return -10;
+        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
+        for (int base = 0; base < niy && status == 0; base += WAVE) {
+            const int iy = base + lane;
+            double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
+            if (iy < niy) {
+                ms_pv nl = nxt;
+                if (niy == 1) {
+                    nl.shock = eg_shock_mean(E, cur, &nl);
+                    pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nl, &terr);
+                } else {
+                    nl.shock = eg_shock_node(E, cur, &nl, b.qz[iy]);
+                    pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nl, &terr);
+                    pr1 *= b.qw[iy];
+                }
+                if (pr1 != 0.0) c1 = eg_term(E, t, cur, &nl, pr1, keep, &t_rhs, &t_evf);
+                shock = nl.shock;
+                cash = nl.cash;
+            }
+            if (__any(terr)) return -25;
+            const int nl_ = min(WAVE, niy - base);
+            for (int l = 0; l < nl_; l++) {  // ordered accumulation
+                const double p = __shfl(pr1, l);
+                if (p == 0.0) continue;
+                checksum += p;
+                cnt++;
+                c1_last = __shfl(c1, l);
+                if (c1_last <= 0) {
+                    status = 1;
+                    *brk_ist = ist1;
+                    *brk_shock = __shfl(shock, l);
+                    *brk_cash = __shfl(cash, l);
+                    break;
+                }
+                rhs += __shfl(t_rhs, l);
+                if (keep == 1) {
+                    evf += __shfl(t_evf, l);
+                    if (evf == -INFINITY) {
+                        status = 2;
+                        *brk_ist = ist1;
+                        *brk_shock = __shfl(shock, l);
+                        *brk_cash = __shfl(cash, l);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    *nev += cnt;
+    *rhs_o = rhs;
+    *evf_o = evf;
+    if (status == 0 && fabs(checksum - 1) > EG_TOL) return -11;
+    return status;
+}
+
+// Head of the guess generator (adraw, egdst_solver.c:955-1099) up to the call that would emit the
+// first point of the closed-form grid.  One wave per (draw, ist, id); all lanes carry the same state.
+__global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
+{
+    const int combo = blockIdx.x;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    if (b.status[draw]) return;
+    const int lane = threadIdx.x;
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = id;
+    cur.cash = cur.savings = cur.shock = 0;
+    ProbeOut *P = &b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    const int act = ms_feasible(&E, &cur) == 1 && ms_inchoiceset(&E, &cur) == 1;
+    if (!act) {
+        if (lane == 0) P->active = 0;
+        return;
+    }
+    const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+    const double a0 = b.g.a0, mmax = b.g.mmax;
+    const size_t co = eg_cand(b, draw, ist, id);
+    // generator state (aspacestruct, :350-367)
+    int ngenerated = 0, ncalls = 0, keep = 0, ntogenerate = b.g.ngridm, np = 0, nev = 0, grid = 0;
+    double baseM = 0, baseA = 0, lim1 = 0, lim2 = 0, lim2p = 0, lim3 = 0, lim3p = 0, k3 = 0, last = 0, M = INFINITY;
+    double evfa0 = 0.0;
+    for (;;) {
+        // ---- next guess -------------------------------------------------------------------
+        if (ncalls + 1 >= b.g.ngridmax) {  // runaway guard (:963-978): the stream simply ends
+            ncalls += 1;
+            break;
+        }
+        if (ngenerated == 0) {
+            ncalls += 1;
+            keep = 0;
+            if (M == INFINITY)
+                last = mmax;
+            else if (M <= mmax) {
+                baseA = last;
+                baseM = M;
+                ngenerated = 1;
+                keep = 1;
+                last = a0;
+                k3 = 0;
+            } else {
+                if (last - a0 < EG_TOL) {
+                    if (lane == 0) eg_fail(b, draw, it, ist, 19);
+                    return;
+                }
+                last = (last + a0) / 2;
+            }
+        } else {
+            double aa = (M - baseM) / (last - baseA);
+            double bb = baseM - aa * baseA;
+            if (ngenerated == 1 && k3 == 0) {  // limits after the first kept call (:1051-1078)
+                ntogenerate = b.g.ngridm;
+                lim2p = MS_MIN(mmax, (mmax - bb) / aa);
+                lim3p = -bb / aa;
+                if (a0 < 0 && a0 < lim3p)
+                    k3 = MS_MAX(floor(ntogenerate * (lim3p - a0) / (lim2p - a0)), 2.0);
+                else {
+                    lim3p = a0;
+                    k3 = 1.0;
+                }
+                lim1 = ms_tr(&E, &cur, lim3p - a0);
+                lim2 = ms_tr(&E, &cur, lim2p - lim3p);
+                lim3 = ms_tr(&E, &cur, 0);
+            }
+            if (M <= a0 - 1 + EG_TOL) {  // c1<=0 signal: resend the prepared point (:1080-1099)
+                ncalls += 1;
+                keep = 1;
+                aa = (a0 - baseM) / (a0 - baseA);
+                bb = baseM - aa * baseA;
+                lim2p = MS_MIN(mmax, (mmax - bb) / aa);
+                lim3p = last - EG_ZEROC;
+                k3 = 1.0;
+                lim1 = ms_tr(&E, &cur, lim3p - a0);
+                lim2 = ms_tr(&E, &cur, lim2p - lim3p);
+                lim3 = ms_tr(&E, &cur, 0);
+            } else {
+                // the next call either starts the closed-form grid (handled by k_grid) or ends the stream
+                grid = (M < mmax && ngenerated < ntogenerate) ? 1 : 0;
+                break;
+            }
+        }
+        // ---- evaluate the guess -----------------------------------------------------------
+        double rhs, evf;
+        int bist = 0;
+        double bshock = 0, bcash = 0;
+        int st = eg_wave_expectation(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash);
+        if (st < 0) {
+            if (lane == 0) eg_fail(b, draw, it, ist, -st);
+            return;
+        }
+        if (st > 0) {  // emergency (:583-627)
+            if (ngenerated == 0) {
+                if (lane == 0) eg_fail(b, draw, it, ist, 12);
+                return;
+            }
+            evfa0 = -INFINITY;
+            M = bcash;
+            if (st == 1) {
+                ms_pv nb;
+                nb.it = it + 1;
+                nb.ist = bist;
+                nb.id = 0;
+                nb.shock = bshock;
+                nb.cash = bcash;
+                nb.savings = last;
+                const Tab tb = eg_tab(b, slot1, draw, bist);
+                int ierr = 0;
+                M = a0 - 1;
+                last = eg_invert_budget(&E, cur, nb, (tb.V[0] > -INFINITY) ? a0 : tb.M[1], &ierr) + EG_ZEROC;
+                if (ierr) {
+                    if (lane == 0) eg_fail(b, draw, it, ist, ierr);
+                    return;
+                }
+            }
+            continue;
+        }
+        rhs *= ms_discount(&E, &cur);
+        M = last + ms_utility_marginal_inverse(&E, &cur, rhs);
+        if (keep == 1 && isfinite(M)) {
+            if (fabs(last - a0) < EG_TOL && evfa0 > -INFINITY) evfa0 = evf;
+            if (lane == 0) {
+                const double c = M - last;
+                b.cM[co] = M;
+                b.cC[co] = c;
+                b.cV[co] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+            }
+            np += 1;  // at most one kept point can precede the grid stage
+        }
+    }
+    if (lane == 0) {
+        P->active = 1;
+        P->np = np;
+        P->grid = grid;
+        P->ncalls = ncalls;
+        P->ntogenerate = ntogenerate;
+        P->probe_evals = nev;
+        P->lim1 = lim1;
+        P->lim2 = lim2;
+        P->lim3 = lim3;
+        P->lim3p = lim3p;
+        P->k3 = k3;
+        P->A0 = last;
+        P->M0 = M;
+        P->evfa0 = evfa0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Closed-form grid point n (1 <= n <= ngridm-1) and its EGM evaluation; one lane per point.
+static __device__ __forceinline__ double eg_grid_target(const ms_env *E, const ms_pv *cur, const ProbeOut &P, int n)
+{
+    // X_n of egdst_solver.c:1110-1119 (n is the value of `ngenerated` at the call)
+    if (n < (int)P.k3 - 1)
+        return -ms_trinv(E, cur, P.lim3 + (P.k3 - 1 - n) * (P.lim1 - P.lim3) / (P.k3 - 1)) + P.lim3p;
+    return ms_trinv(E, cur, P.lim3 + (n - P.k3 + 1) * (P.lim2 - P.lim3) / (P.ntogenerate - P.k3)) + P.lim3p;
+}
+
+__global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
+{
+    const int combo = blockIdx.y;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
+    if (b.status[draw]) return;
+    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    if (!P.active || !P.grid || n >= b.g.ngridm) return;
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = id;
+    cur.cash = cur.savings = cur.shock = 0;
+    // The reference advances A by steps: A_n = A_{n-1} + (X_n - A_{n-1}) with a floor on negative steps
+    // (:1120-1136).  Whenever X_n and A_{n-1} are within a factor two of each other the step is exact and
+    // A_n == X_n, so the chain only needs to be followed back to the last such point.
+    double A;
+    {
+        int k = n;
+        while (k > 1) {  // find a start whose predecessor makes the step exact
+            double xk = eg_grid_target(&E, &cur, P, k - 1), xk1 = eg_grid_target(&E, &cur, P, k);
+            const bool same = (xk > 0 && xk1 > 0) || (xk < 0 && xk1 < 0);
+            if ((same && fabs(xk1) <= 2 * fabs(xk) && fabs(xk) <= 2 * fabs(xk1)) || n - k >= 8) break;  // A_k == X_k
+            k--;
+        }
+        double prev = (k == 1) ? P.A0 : eg_grid_target(&E, &cur, P, k - 1);
+        for (int j = k; j <= n; j++) {
+            double step = eg_grid_target(&E, &cur, P, j) - prev;
+            if (step < 0) step = MS_MAX(step, 1e-5);
+            prev += step;
+        }
+        A = prev;
+    }
+    const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+    const int ny = b.g.ny;
+    double rhs = 0, evf = 0, checksum = 0, c1 = 1.0, bcash = 0;
+    int status = 0, terr = 0, cnt = 0;
+    ms_pv nxt;
+    nxt.it = it + 1;
+    nxt.id = 0;
+    nxt.cash = 0;
+    nxt.shock = 0;
+    nxt.savings = A;
+    for (nxt.ist = 0; nxt.ist < MS_NST; nxt.ist++) {
+        if (ms_feasible(&E, &nxt) != 1) continue;
+        double pr1pre = 0;
+        if (MS_OPTIM_TRPRNOSH) {
+            pr1pre = ms_trpr(&E, &cur, &nxt, &terr);
+            if (pr1pre == 0.0) continue;
+        }
+        const int niy = (ms_sigma(&E, &cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
+        const Tab t = eg_tab(b, slot1, draw, nxt.ist);
+        if (t.len < 2) {
+            status = -10;
+            break;
+        }
+        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) {
+            status = -2707;
+            break;
+        }
+        for (int iy = 0; iy < niy; iy++) {
+            double pr1;
+            if (niy == 1) {
+                nxt.shock = eg_shock_mean(&E, &cur, &nxt);
+                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
+            } else {
+                nxt.shock = eg_shock_node(&E, &cur, &nxt, b.qz[iy]);
+                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
+                pr1 *= b.qw[iy];
+            }
+            if (pr1 == 0.0) continue;
+            checksum += pr1;
+            cnt++;
+            double t_rhs, t_evf;
+            c1 = eg_term(&E, t, &cur, &nxt, pr1, 1, &t_rhs, &t_evf);
+            if (c1 <= 0) break;
+            rhs += t_rhs;
+            evf += t_evf;
+            if (evf == -INFINITY) break;
+        }
+        if (c1 <= 0 || evf == -INFINITY) {
+            bcash = nxt.cash;
+            break;
+        }
+    }
+    const size_t o = eg_cand(b, draw, ist, id) + n;
+    if (terr) status = -25;
+    if (status == 0) {
+        if (c1 <= 0)
+            status = 1;
+        else if (evf == -INFINITY)
+            status = 2;
+        else if (fabs(checksum - 1) > EG_TOL)
+            status = -11;
+    }
+    b.cCnt[o] = cnt;
+    b.cSt[o] = status;
+    if (status == 0) {
+        rhs *= ms_discount(&E, &cur);
+        const double M = A + ms_utility_marginal_inverse(&E, &cur, rhs);
+        const double c = M - A;
+        b.cR[o] = M;
+        b.cM[o] = M;
+        b.cC[o] = c;
+        b.cV[o] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+    } else {
+        b.cR[o] = (status == 1) ? b.g.a0 - 1 : bcash;  // what the generator is told (:595-599)
+        b.cM[o] = NAN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide helpers (ENV_BS threads)
+static __device__ __forceinline__ int blk_min(int v, int *sh)
+{
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = ENV_BS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = min(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    return sh[0];
+}
+static __device__ __forceinline__ int blk_sum(int v, int *sh)
+{
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = ENV_BS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sh[0];
+}
+// exclusive scan of one flag per thread; returns the exclusive prefix, *total the block total
+static __device__ __forceinline__ int blk_scan(int v, int *sh, int *total)
+{
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < ENV_BS; s <<= 1) {
+        int t = ((int)threadIdx.x >= s) ? sh[threadIdx.x - s] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    *total = sh[ENV_BS - 1];
+    return sh[threadIdx.x] - v;
+}
+
+// strict order of comp1 (egdst_solver.c:1570-1582) extended by the original index (qsort of glibc is a
+// stable merge sort, so fully tied quadruples keep their input order)
+static __device__ __forceinline__ bool pt_before(double am, double av, int af, int ai, double bm, double bv, int bf, int bi)
+{
+    if (am != bm) return am < bm;
+    if (av != bv) return av > bv;
+    if (af != bf) return af < bf;
+    return ai < bi;
+}
+
+// Sort npts points of nf functions (function f occupies [fstart[f], fstart[f]+dims[f]) of the input) into
+// (om,oc,ov,of) and record rank[].  Each function's list is normally already ordered, so the rank of a point
+// is a sum of binary searches (a merge); an unordered list falls back to counting.
+static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const double *im, const double *ic, const double *iv, const int *ifn,
+                                     const int *fstart, const int *dims, double *om, double *oc, double *ov, int *of,
+                                     int *rank, int *sh, int *oob, int *dbg)
+{
+    int bad = 0;
+    for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
+        if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
+    bad = blk_sum(bad, sh);
+    for (int i = threadIdx.x; i < npts; i += ENV_BS) {
+        const double m = im[i], v = iv[i];
+        const int f = ifn[i];
+        int r = 0;
+        if (!bad) {
+            for (int g = 0; g < nf; g++) {
+                const int dg = dims[g];
+                if (dg <= 0) continue;
+                const int s = fstart[g];
+                if (g == f) {
+                    r += i - s;
+                    continue;
+                }
+                int lo = 0, hi = dg;  // first index of g that is not before (m,v,f)
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (pt_before(im[s + mid], iv[s + mid], g, s + mid, m, v, f, i))
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                r += lo;
+            }
+        } else {
+            for (int j = 0; j < npts; j++)
+                if (pt_before(im[j], iv[j], ifn[j], j, m, v, f, i)) r++;
+        }
+        if (r < 0 || r >= npts) {
+            *oob = 1;
+            continue;
+        }
+        rank[i] = r;
+        om[r] = m;
+        oc[r] = ic[i];
+        ov[r] = v;
+        of[r] = f;
+    }
+    __syncthreads();
+#ifdef EGDST_VERIFY_SORT
+    // diagnostic build: the output must be a permutation of the input in comp1 order
+    for (int i = threadIdx.x; i < npts; i += ENV_BS) {
+        int r = rank[i];
+        bool okp = (of[r] == ifn[i]) && (om[r] == im[i] || (om[r] != om[r] && im[i] != im[i]));
+        bool oks = (i == 0) || pt_before(om[i - 1], ov[i - 1], of[i - 1], 0, om[i], ov[i], of[i], 1);
+        if ((!okp || !oks) && dbg && atomicCAS(&dbg[0], 0, 2720 + (okp ? 1 : 0)) == 0) {
+            dbg[1] = i, dbg[2] = r, dbg[3] = npts, dbg[4] = nf, dbg[5] = bad, dbg[6] = ifn[i], dbg[7] = of[r];
+            dbg[8] = dims[0], dbg[9] = fstart[0], dbg[10] = nf > 1 ? dims[1] : -1, dbg[11] = nf > 1 ? fstart[1] : -1;
+            dbg[12] = nf > 2 ? dims[2] : -1, dbg[13] = nf > 2 ? fstart[2] : -1;
+            dbg[14] = (im[i] != im[i]) * 1 + (iv[i] != iv[i]) * 2 + (i > 0 ? (of[i - 1] * 10) : 0);
+            dbg[15] = i > 0 ? of[i] : -1;
+            *oob = 1;
+        }
+    }
+    __syncthreads();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stop rule, compaction, secondary and primary envelopes, output rows for one (draw, ist).
+#define ENV_FAIL(code)                                   \
+    do {                                                 \
+        if (tid == 0) {                                  \
+            eg_fail(b, draw, it, ist, (code));           \
+            b.tlen[tk] = b.tthlen[tk] = 0;               \
+        }                                                \
+        return;                                          \
+    } while (0)
+__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal)
+{
+    __shared__ int sh[ENV_BS];
+    __shared__ double s_evfa0[MS_ND];
+    __shared__ int s_cnt[MS_ND], s_start[MS_ND];
+    __shared__ int s_err, s_n, s_m, s_oob;
+    const int ist = blockIdx.x % MS_NST, draw = blockIdx.x / MS_NST;
+    const int tid = threadIdx.x;
+    const int slot = (b.g.nslots == 2) ? (it & 1) : it;
+    const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    if (b.status[draw]) {
+        if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        return;
+    }
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = 0;
+    cur.cash = cur.savings = cur.shock = 0;
+    if (ms_feasible(&E, &cur) != 1) {
+        if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        return;
+    }
+    const int ngridmax = b.g.ngridmax, ngridm = b.g.ngridm;
+    const double mmax = b.g.mmax;
+    const size_t W = (size_t)(MS_ND + 1) * ngridmax, wo = ((size_t)draw * MS_NST + ist) * W;
+    double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
+    int *pF = b.pF + wo;
+    double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
+    int *sF = b.sF + wo;
+    int *rank = b.rank + wo;
+    const size_t fo = ((size_t)draw * MS_NST + ist) * (size_t)(ngridmax + MS_ND + 2);
+    int *fstart = b.fstart + fo, *fdims = b.fdims + fo, *fcur = b.fcur + fo, *fmark = b.fmark + fo;
+    const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)ngridmax;
+    double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eo, *eIX = b.eIX + eo;
+    int *stack = b.stack + 2 * eo;
+    // third buffer for sorted points: reuse the candidate arrays of this (draw, ist) -- they hold
+    // MS_ND*ngridmax entries; sorted input can reach (MS_ND+1)*ngridmax only in the secondary envelope of
+    // a single choice, where at most 2*ngridmax are live, so sorting goes to the `q` views below.
+    double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
+    int *qF = b.qF + wo;
+
+    if (tid == 0) s_err = 0, s_oob = 0;
+    __syncthreads();
+    int any = 0, nall = 0;
+    unsigned long long evals = 0;
+    for (int id = 0; id < MS_ND; id++) {
+        __syncthreads();
+        if (tid == 0) {
+            s_cnt[id] = 0;
+            s_start[id] = nall;
+            s_evfa0[id] = 0.0;
+        }
+        const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+        if (!P.active) continue;
+        any = 1;
+        const size_t co = eg_cand(b, draw, ist, id);
+        int nreq = 0;
+        double evfa0 = P.evfa0;
+        if (terminal) {
+            nreq = ngridm - 1;  // candidate indices 0..ngridm-1, all kept
+        } else {
+            const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
+            // first requested point whose returned M stops the stream (:1100): the point itself is kept
+            int first = navail + 1;
+            for (int n = 1 + tid; n <= navail; n += ENV_BS)
+                if (!(b.cR[co + n] < mmax)) {
+                    first = n;
+                    break;
+                }
+            first = blk_min(first, sh);
+            nreq = min(first, navail);
+            int hard = 0, n1 = 0, n2 = 0, ev = 0;
+            for (int n = 1 + tid; n <= nreq; n += ENV_BS) {
+                const int st = b.cSt[co + n];
+                if (st < 0) hard = max(hard, -st);
+                n1 += (st == 1);
+                n2 += (st == 2);
+                ev += b.cCnt[co + n];
+            }
+            hard = -blk_min(-hard, sh);
+            n1 = blk_sum(n1, sh);
+            n2 = blk_sum(n2, sh);
+            ev = blk_sum(ev, sh);
+            evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
+            if (hard) ENV_FAIL(hard);
+            if (n1) ENV_FAIL(26);  // c1<=0 inside the grid stage: the reference would resend from there
+            if (n2) evfa0 = -INFINITY;
+        }
+        // ---- compaction of kept points into the choice's list ----------------------------------
+        int cnt = 0;
+        {
+            int carry = 0;
+            for (int base = 0; base <= nreq; base += ENV_BS) {
+                const int n = base + tid;
+                int keepit = 0;
+                if (n <= nreq) {
+                    if (terminal)
+                        keepit = 1;
+                    else if (n == 0)
+                        keepit = P.np;
+                    else
+                        keepit = (b.cSt[co + n] == 0 && isfinite(b.cM[co + n]));
+                }
+                int tot;
+                const int ex = blk_scan(keepit, sh, &tot);
+                if (keepit) {
+                    const int d = nall + carry + ex;
+                    if (d < 0 || (size_t)d >= W)
+                        s_oob = 1;
+                    else {
+                        pM[d] = b.cM[co + n];
+                        pC[d] = b.cC[co + n];
+                        pV[d] = b.cV[co + n];
+                        pF[d] = id;
+                    }
+                }
+                carry += tot;
+            }
+            cnt = carry;
+        }
+        __syncthreads();
+        if (s_oob) ENV_FAIL(2705);
+        // ---- secondary envelope (:776-913) ------------------------------------------------------
+        if (!terminal && cnt > 1) {
+            int nfold = 0;
+            for (int i = 1 + tid; i < cnt; i += ENV_BS)
+                if (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]) nfold++;
+            nfold = blk_sum(nfold, sh);
+            if (nfold > 0) {
+                // input with one constant-extrapolation point appended to every closed piece (:822-835)
+                int carry = 0, lastfold = 0;
+                for (int base = 0; base < cnt; base += ENV_BS) {
+                    const int i = base + tid;
+                    int fold = 0;
+                    if (i >= 1 && i < cnt)
+                        fold = (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]);
+                    int tot;
+                    const int ex = blk_scan(fold, sh, &tot);
+                    if (i < cnt) {
+                        const int sidx = carry + ex + fold;  // pieces closed before this point
+                        const int d = i + sidx;
+                        if ((size_t)d >= W || id + sidx >= ngridmax + MS_ND + 2)
+                            s_oob = 1;
+                        else {
+                            sM[d] = pM[nall + i];
+                            sC[d] = pC[nall + i];
+                            sV[d] = pV[nall + i];
+                            sF[d] = id + sidx;
+                            if (fold) {
+                                sM[d - 1] = 1.5 * mmax;
+                                sC[d - 1] = pC[nall + i - 1];
+                                sV[d - 1] = pV[nall + i - 1];
+                                sF[d - 1] = id + sidx - 1;
+                                fstart[id + sidx] = d;
+                                if (sidx == nfold) lastfold = i;
+                            }
+                        }
+                        if (i == 0) fstart[id] = 0;
+                    }
+                    carry += tot;
+                }
+                lastfold = blk_sum(lastfold, sh);
+                if (s_oob) ENV_FAIL(2706);
+                const int total = cnt + nfold, nf = id + nfold + 1;
+                if (lastfold + (nfold - 1) >= ngridmax) ENV_FAIL(17);
+                if (id + nfold >= 10000) ENV_FAIL(18);
+                __syncthreads();
+                for (int f = tid; f < nf; f += ENV_BS) {
+                    if (f < id)
+                        fdims[f] = 0, fstart[f] = 0;
+                    else
+                        fdims[f] = ((f + 1 < nf) ? fstart[f + 1] : total) - fstart[f];
+                }
+                __syncthreads();
+                blk_rank_sort(total, nf, sM, sC, sV, sF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw);
+                if (s_oob) ENV_FAIL(2704);
+                if (tid == 0) {
+                    EnvCtx e;
+                    e.E = &E;
+                    e.it = it;
+                    e.ist = ist;
+                    e.nf = nf;
+                    e.m = qM;
+                    e.c = qC;
+                    e.v = qV;
+                    e.f = qF;
+                    e.rank = rank;
+                    e.fstart = fstart;
+                    e.dims = fdims;
+                    e.cur = fcur;
+                    e.mark = fmark;
+                    e.stack = stack;
+                    e.stackcap = 2 * ngridmax;
+                    e.evfa0 = nullptr;
+                    e.sec_id = id;
+                    e.sec_ev = evfa0;
+                    e.og = eM;
+                    e.ov = eV;
+                    e.oc = eC;
+                    e.oth = eTH;
+                    e.oix = eIX;
+                    e.ngridmax = ngridmax;
+                    e.nthrhmax = b.g.nthrhmax;
+                    e.cap = (int)W;
+                    e.npts = total;
+                    e.dbg = b.dbg + 16 * draw;
+                    e.err = 0;
+                    env_walk(e, total);
+                    if (!e.err && e.oi >= ngridmax) e.err = 17;  // (:884)
+                    s_err = e.err;
+                    s_n = e.oi;
+                }
+                __syncthreads();
+                if (s_err) ENV_FAIL(s_err);
+                cnt = s_n;
+                for (int i = tid; i < cnt; i += ENV_BS) {
+                    pM[nall + i] = eM[i];
+                    pC[nall + i] = eC[i];
+                    pV[nall + i] = eV[i];
+                    pF[nall + i] = id;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            s_cnt[id] = cnt;
+            s_evfa0[id] = evfa0;
+        }
+        nall += cnt;
+    }
+    __syncthreads();
+    if (!any) ENV_FAIL(14);
+    if (nall == 0) ENV_FAIL(15);
+    // ---- primary envelope across choices (:720, :1165-1550) ---------------------------------------
+    double *oM = b.tM + tk * b.g.S, *oC = b.tC + tk * b.g.S, *oV = b.tV + tk * b.g.S;
+    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
+    int nact = 0, fsingle = -1;
+    for (int id = 0; id < MS_ND; id++)
+        if (s_cnt[id] > 0) nact++, fsingle = id;
+    int outn = 0, outm = 0, done = 0;
+    if (nact == 1) {
+        // a single tabulated function: the walk keeps every point except repeats of a grid value,
+        // provided the list is already in comp1 order (it is unless M ties carry increasing V)
+        int bad = 0;
+        for (int i = 1 + tid; i < nall; i += ENV_BS)
+            if (pM[i - 1] > pM[i] || (pM[i - 1] == pM[i] && pV[i - 1] < pV[i])) bad = 1;
+        bad = blk_sum(bad, sh);
+        if (!bad) {
+            int carry = 0;
+            for (int base = 0; base < nall; base += ENV_BS) {
+                const int i = base + tid;
+                const int keepit = (i < nall) && (i == 0 || pM[i] != pM[i - 1]);
+                int tot;
+                const int ex = blk_scan(keepit, sh, &tot);
+                if (keepit) {
+                    const int d = 1 + carry + ex;
+                    oM[d] = pM[i];
+                    oC[d] = pC[i];
+                    oV[d] = pV[i];
+                }
+                carry += tot;
+            }
+            outn = carry;
+            outm = 1;
+            if (tid == 0) {
+                oTH[0] = b.g.a0;
+                oD[0] = fsingle;
+            }
+            done = 1;
+            if (outn >= ngridmax || 1 >= b.g.nthrhmax) ENV_FAIL(outn >= ngridmax ? 13 : 20);
+        }
+    }
+    if (!done) {
+        for (int f = tid; f < MS_ND; f += ENV_BS) {
+            fstart[f] = s_start[f];
+            fdims[f] = s_cnt[f];
+        }
+        __syncthreads();
+        blk_rank_sort(nall, MS_ND, pM, pC, pV, pF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw);
+        if (s_oob) ENV_FAIL(2714);
+        if (tid == 0) {
+            EnvCtx e;
+            e.E = &E;
+            e.it = it;
+            e.ist = ist;
+            e.nf = MS_ND;
+            e.m = qM;
+            e.c = qC;
+            e.v = qV;
+            e.f = qF;
+            e.rank = rank;
+            e.fstart = fstart;
+            e.dims = fdims;
+            e.cur = fcur;
+            e.mark = fmark;
+            e.stack = stack;
+            e.stackcap = 2 * ngridmax;
+            e.evfa0 = s_evfa0;
+            e.sec_id = -1;
+            e.sec_ev = 0;
+            e.og = oM + 1;
+            e.ov = oV + 1;
+            e.oc = oC + 1;
+            e.oth = oTH;
+            e.oix = oD;
+            e.ngridmax = ngridmax;
+            e.nthrhmax = b.g.nthrhmax;
+            e.cap = (int)W;
+            e.npts = nall;
+            e.dbg = b.dbg + 16 * draw;
+            e.err = 0;
+            env_walk(e, nall);
+            if (!e.err && e.oi == 0) e.err = 16;
+            s_err = e.err;
+            s_n = e.oi;
+            s_m = e.oj;
+        }
+        __syncthreads();
+        if (s_err) ENV_FAIL(s_err);
+        outn = s_n;
+        outm = s_m;
+    }
+    // ---- row 0 and lengths (saveoutput :917-952; evf(a0) :730) ------------------------------------
+    if (tid == 0) {
+        oM[0] = b.g.a0;
+        oC[0] = 0;
+        oV[0] = s_evfa0[(int)oD[0]];
+        b.tlen[tk] = outn + 1;
+        b.tthlen[tk] = outm;
+        if (evals) atomicAdd(&b.evals[draw], evals);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward simulation, one lane per agent (egdst_simulator.c:204-383, policy :145-199, output :122-143).
+struct SimArgs {
+    int draw, nsim, rndtype, nout;
+    const double *init;        // [nsim x 2] column-major
+    const double *randstream;  // uniforms
+    double *sims;              // [nout x nt x nsim]
+    int *err;
+};
+
+__global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
+{
+    const int isim = blockIdx.x * GRID_BS + threadIdx.x;
+    if (isim >= a.nsim) return;
+    const int nt = b.g.nt, draw = a.draw;
+    ms_env E = eg_env(b, draw);
+    const double *rs = a.rndtype == 1 ? a.randstream : a.randstream + 4LL * nt * isim;
+    const int ist0 = (int)a.init[isim] - 1;
+    const double m0 = a.init[a.nsim + isim];
+    if (ist0 < 0 || ist0 >= MS_NST) return;
+    if (m0 < b.g.a0 || m0 > b.g.mmax) return;
+    ms_pv cp, np_;
+    double mu = NAN, sigma = NAN, eqs[MS_NEQ + 1];
+    int irnd = 0, terr = 0;
+    cp.it = 0;
+    cp.ist = ist0;
+    cp.id = 0;
+    cp.cash = m0;
+    cp.savings = 0;
+    cp.shock = NAN;
+    for (int it = 0; it < nt; it++) {
+        if (it == 0) {
+            if (!ms_feasible(&E, &cp)) return;
+            ms_eqs_sim(&E, &cp, &cp, 0, eqs);
+        } else {
+            np_.it = it;
+            np_.id = 0;
+            np_.cash = 0;
+            np_.shock = 0;
+            np_.savings = cp.savings;
+            double r0 = rs[irnd++];
+            const double r1 = rs[irnd++], r2 = rs[irnd++];
+            if (r2 > ms_survival(&E, &cp)) return;  // death: remaining periods stay NaN
+            double pr = 0;
+            for (np_.ist = 0; np_.ist < MS_NST; np_.ist++) {
+                if (!ms_feasible(&E, &np_)) continue;
+                if (MS_OPTIM_TRPRNOSH)
+                    pr = ms_trpr(&E, &cp, &np_, &terr);
+                else {
+                    mu = ms_mu(&E, &cp, &np_);
+                    sigma = ms_sigma(&E, &cp, &np_);
+                    np_.shock = (sigma <= 0) ? eg_shock_mean(&E, &cp, &np_) : eg_shock_uniform(r1, mu, sigma);
+                    pr = ms_trpr(&E, &cp, &np_, &terr);
+                }
+                r0 -= pr;
+                if (r0 <= 0) break;
+            }
+            if (np_.ist >= MS_NST) {
+                atomicCAS(a.err, 0, EGDST_E_SIM_STATE);
+                return;
+            }
+            if (MS_OPTIM_TRPRNOSH) {
+                mu = ms_mu(&E, &cp, &np_);
+                sigma = ms_sigma(&E, &cp, &np_);
+                np_.shock = (sigma <= 0) ? eg_shock_mean(&E, &cp, &np_) : eg_shock_uniform(r1, mu, sigma);
+            }
+            np_.cash = ms_cashinhand(&E, &cp, &np_);
+            ms_eqs_sim(&E, &cp, &np_, 1, eqs);
+            cp = np_;
+        }
+        // policy at (it, ist)
+        const Tab t = eg_tab(b, it, draw, cp.ist);
+        if (t.len < 2) {
+            atomicCAS(a.err, 0, EGDST_E_NOT_SOLVED);
+            return;
+        }
+        const int i = eg_bracket(cp.cash, t.M, t.len, 0);
+        const double c = eg_lerp(cp.cash, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
+        cp.savings = cp.cash - c;
+        int ith = 0;
+        while (ith < t.thlen && cp.cash >= t.TH[ith]) ith++;
+        cp.id = (int)t.D[max(ith - 1, 0)];
+        double vf;
+        if (cp.cash < t.M[1] && t.V[0] > -INFINITY)
+            vf = ms_utility(&E, &cp, c) + ms_discount(&E, &cp) * t.V[0];
+        else
+            vf = eg_lerp(cp.cash, t.M[i], t.M[i + 1], t.V[i], t.V[i + 1]);
+        double *o = a.sims + ((size_t)isim * nt + it) * a.nout;
+        o[0] = cp.cash;
+        o[1] = c;
+        o[2] = cp.savings;
+        o[3] = vf;
+        o[4] = (double)cp.id;
+        o[5] = (double)cp.ist;
+        o[6] = mu;
+        o[7] = sigma;
+        o[8] = cp.shock;
+        o[9] = ms_utility(&E, &cp, c);
+        o[10] = ms_discount(&E, &cp);
+        for (int k = 0; k < MS_NNST; k++) o[11 + k] = ms_states[cp.ist + k * MS_NST];
+        for (int k = 0; k < MS_NND; k++) o[11 + MS_NNST + k] = ms_decisions[cp.id + k * MS_ND];
+        for (int k = 0; k < MS_NEQ; k++) o[11 + MS_NNST + MS_NND + k] = eqs[k];
+    }
+    if (terr) atomicCAS(a.err, 0, EGDST_E_TRPR_CASES);
+}
+
+__global__ void k_fill_nan(double *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (i == 0) ? 0.0 : NAN;  // NaN fill starts at element 1 (egdst_simulator.c:105)
+}
+
+#include "egdst_host.inc"

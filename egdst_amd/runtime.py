@@ -1,0 +1,250 @@
+"""ctypes binding of the per-model C ABI (include/egdst.h) + the solve/sim plumbing of the class.
+
+No torch types cross the boundary; torch is only used by callers that want device-resident
+parameter batches (``Solver.set_params_torch``).  There is no CPU fallback: if the HIP library
+cannot be loaded, or no GPU is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+
+class EgdstDesc(C.Structure):
+    _fields_ = [('t0', C.c_int), ('T', C.c_int), ('ngridm', C.c_int), ('ngridmax', C.c_int),
+                ('nthrhmax', C.c_int), ('ny', C.c_int), ('mmax', C.c_double), ('a0', C.c_double),
+                ('quadrature', C.POINTER(C.c_double))]
+
+
+class EgdstModelInfo(C.Structure):
+    _fields_ = [('nst', C.c_int), ('nd', C.c_int), ('nnst', C.c_int), ('nnd', C.c_int), ('nparam', C.c_int),
+                ('neq', C.c_int), ('distrib', C.c_int), ('optim_MUnoD', C.c_int), ('optim_UnoD', C.c_int),
+                ('optim_UasD', C.c_int), ('optim_TRPRnoSH', C.c_int), ('tolerance', C.c_double),
+                ('zeroconsumption', C.c_double), ('doublepoint_delta', C.c_double), ('label', C.c_char_p)]
+
+
+# every symbol include/egdst.h declares (checked by the CPU test-suite against the header)
+ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'egdst_create', 'egdst_destroy',
+               'egdst_set_params', 'egdst_set_params_dev', 'egdst_solve_async', 'egdst_sync', 'egdst_solve',
+               'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
+               'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug']
+
+
+class EgdstRuntimeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('egdst error %d: %s' % (code, msg))
+        self.code = code
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class ModelLibrary:
+    """One loaded per-model shared library."""
+
+    def __init__(self, path, tag=''):
+        if not os.path.exists(path):
+            raise EgdstRuntimeError(3, 'HIP library %s is missing: run model.compile() (no CPU fallback exists)' % path)
+        self.path, self.tag = path, tag
+        self.lib = C.CDLL(path, mode=getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2))
+        L = self.lib
+        for s in ABI_SYMBOLS:
+            getattr(L, s)  # AttributeError if the library does not export what the header declares
+        L.egdst_strerror.restype = C.c_char_p
+        L.egdst_last_error.restype = C.c_char_p
+        L.egdst_create.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.egdst_destroy.argtypes = [C.c_void_p]
+        L.egdst_set_params.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.egdst_set_params_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.egdst_solve_async.argtypes = [C.c_void_p]
+        L.egdst_sync.argtypes = [C.c_void_p]
+        L.egdst_solve.argtypes = [C.c_void_p]
+        L.egdst_get_status.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.egdst_get_evals.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.egdst_cell_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.egdst_get_cell_M.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_get_cell_D.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_get_solution.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + \
+            [C.POINTER(C.c_double)] * 5
+        L.egdst_simulate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
+                                     C.c_longlong, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_get_debug.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.egdst_device_tables.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4
+        info = EgdstModelInfo()
+        L.egdst_get_model_info(C.byref(info))
+        self.info = info
+
+    def check(self, rc):
+        if rc != 0:
+            raise EgdstRuntimeError(rc, (self.lib.egdst_last_error() or b'').decode(errors='replace'))
+
+
+class Solution:
+    """Host copy of one draw's solution in the table layout shared with the oracle harness."""
+
+    def __init__(self, nt, nst, ngridmax, nthrhmax):
+        self.nt, self.nst = nt, nst
+        self.M = np.zeros((nt, nst, ngridmax + 1))
+        self.C = np.zeros((nt, nst, ngridmax + 1))
+        self.V = np.zeros((nt, nst, ngridmax + 1))
+        self.D = np.zeros((nt, nst, nthrhmax))
+        self.TH = np.zeros((nt, nst, nthrhmax))
+        self.len = np.zeros((nt, nst), dtype=np.int32)
+        self.thlen = np.zeros((nt, nst), dtype=np.int32)
+        self.nevals = 0
+        self.status = 0
+        self.where = (0, 0)
+        self.err = ''
+
+    def cell_M(self, it, ist):
+        n = self.len[it, ist]
+        m, c, v = self.M[it, ist, :n], self.C[it, ist, :n], self.V[it, ist, :n]
+        return np.stack([m, c, m - c, v], axis=1)
+
+    def cell_D(self, it, ist):
+        n = self.thlen[it, ist]
+        return np.stack([self.D[it, ist, :n], self.TH[it, ist, :n]], axis=1)
+
+    def total_rows(self):
+        return int(self.len.sum())
+
+    def cells(self):
+        """(M, D) as nst x nt nested lists of matrices: the MATLAB cell arrays of solve (empty = None)."""
+        M = [[self.cell_M(it, ist) if self.len[it, ist] else None for it in range(self.nt)] for ist in range(self.nst)]
+        D = [[self.cell_D(it, ist) if self.len[it, ist] else None for it in range(self.nt)] for ist in range(self.nst)]
+        return M, D
+
+
+class Solver:
+    """A device-resident batch of `ndraw` independent solves of one compiled model."""
+
+    def __init__(self, lib: ModelLibrary, desc: dict, ndraw=1, keep_history=True, stream=None):
+        self.lib, self.ndraw, self.keep_history = lib, int(ndraw), bool(keep_history)
+        self._quad = np.ascontiguousarray(desc['quadrature'], dtype=np.float64)
+        ngridmax = desc['ngridmax'] if desc['ngridmax'] > desc['ngridm'] else 2 * desc['ngridm']
+        self.desc = dict(desc, ngridmax=ngridmax)
+        d = EgdstDesc(desc['t0'], desc['T'], desc['ngridm'], ngridmax, desc['nthrhmax'], desc['ny'],
+                      desc['mmax'], desc['a0'], _dp(self._quad))
+        self.nt = desc['T'] - desc['t0'] + 1
+        self.h = C.c_void_p()
+        lib.check(lib.lib.egdst_create(C.byref(d), self.ndraw, int(self.keep_history),
+                                       C.c_void_p(stream) if stream else None, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.lib.egdst_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(self.ndraw, -1))
+        if p.shape[1] != self.lib.info.nparam:
+            raise EgdstRuntimeError(1, 'expected %d parameters per draw, got %d' % (self.lib.info.nparam, p.shape[1]))
+        self.lib.check(self.lib.lib.egdst_set_params(self.h, _dp(p), self.ndraw))
+
+    def set_params_dev(self, dev_ptr):
+        self.lib.check(self.lib.lib.egdst_set_params_dev(self.h, C.c_void_p(dev_ptr), self.ndraw))
+
+    def solve_async(self):
+        self.lib.check(self.lib.lib.egdst_solve_async(self.h))
+
+    def sync(self, raise_on_error=True):
+        rc = self.lib.lib.egdst_sync(self.h)
+        if rc and (raise_on_error or rc < 10):
+            self.lib.check(rc)
+        return rc
+
+    def solve(self, raise_on_error=True):
+        self.solve_async()
+        return self.sync(raise_on_error)
+
+    def status(self):
+        st = np.zeros(self.ndraw, dtype=np.int32)
+        wh = np.zeros(2 * self.ndraw, dtype=np.int32)
+        self.lib.check(self.lib.lib.egdst_get_status(self.h, _ip(st), _ip(wh)))
+        return st, wh.reshape(self.ndraw, 2)
+
+    def evals(self):
+        tot = C.c_longlong(0)
+        per = np.zeros(self.ndraw, dtype=np.int64)
+        self.lib.check(self.lib.lib.egdst_get_evals(self.h, C.byref(tot), per.ctypes.data_as(C.POINTER(C.c_longlong))))
+        return int(tot.value), per
+
+    def solution(self, draw=0):
+        d = self.desc
+        sol = Solution(self.nt, self.lib.info.nst, d['ngridmax'], d['nthrhmax'])
+        self.lib.check(self.lib.lib.egdst_get_solution(self.h, draw, _ip(sol.len), _ip(sol.thlen), _dp(sol.M),
+                                                       _dp(sol.C), _dp(sol.V), _dp(sol.D), _dp(sol.TH)))
+        st, wh = self.status()
+        sol.status, sol.where = int(st[draw]), tuple(int(x) for x in wh[draw])
+        sol.err = self.lib.lib.egdst_strerror(sol.status).decode() if sol.status else ''
+        sol.nevals = int(self.evals()[1][draw])
+        return sol
+
+    def debug(self, draw=0):
+        out = np.zeros(16, dtype=np.int32)
+        self.lib.check(self.lib.lib.egdst_get_debug(self.h, draw, _ip(out)))
+        return out
+
+    def cell_M(self, draw, it, ist):
+        n, nth = C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.lib.egdst_cell_dims(self.h, draw, it, ist, C.byref(n), C.byref(nth)))
+        out = np.zeros((4, n.value))
+        if n.value:
+            self.lib.check(self.lib.lib.egdst_get_cell_M(self.h, draw, it, ist, _dp(out)))
+        return np.ascontiguousarray(out.T)  # column-major (len x 4) -> rows
+
+    def cell_D(self, draw, it, ist):
+        n, nth = C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.lib.egdst_cell_dims(self.h, draw, it, ist, C.byref(n), C.byref(nth)))
+        out = np.zeros((2, nth.value))
+        if nth.value:
+            self.lib.check(self.lib.lib.egdst_get_cell_D(self.h, draw, it, ist, _dp(out)))
+        return np.ascontiguousarray(out.T)
+
+    def simulate(self, init, randstream, rndtype=0, draw=0):
+        init = np.asfortranarray(np.atleast_2d(np.asarray(init, dtype=np.float64)))
+        nsim = init.shape[0]
+        info = self.lib.info
+        nout = 11 + info.nnst + info.nnd + info.neq
+        sims = np.zeros((nsim, self.nt, nout))  # C order == column-major [nout x nt x nsim]
+        rs = np.ascontiguousarray(randstream, dtype=np.float64)
+        self.lib.check(self.lib.lib.egdst_simulate(self.h, draw, _dp(init), nsim, _dp(rs), rs.size, int(rndtype),
+                                                   _dp(sims)))
+        return sims
+
+
+def solve_model(model):
+    """model.solve(): one draw with the model's current parameters, history kept for sim/export."""
+    desc = model.descriptor()
+    if model.__dict__.get('_solver') is not None:
+        model._solver.close()
+    s = Solver(model._lib, desc, ndraw=1, keep_history=True)
+    model.__dict__['_solver'] = s
+    s.set_params(model.param_vector())
+    rc = s.solve(raise_on_error=False)
+    sol = s.solution(0)
+    if rc:
+        # the reference warns and returns the partially filled cells (egdst_solver.c:237)
+        import warnings
+        warnings.warn(sol.err)
+    return sol
+
+
+def simulate_model(model, rndtype):
+    s = model.__dict__.get('_solver')
+    if s is None:
+        raise EgdstRuntimeError(40, 'Error: the model has not yet been solved!')
+    return s.simulate(model.init, model.randstream, rndtype, draw=0)

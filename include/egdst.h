@@ -1,0 +1,130 @@
+/*
+ * egdst.h -- C ABI of the MI355X-native egdst hot path (one shared library PER MODEL).
+ *
+ * The reference builds three MEX files per model (compile.m:781,793,805) and calls them as
+ *     [M,D,dbgout] = egdst_solver(model)        @egdstmodel/egdstmodel.m:1170  -> egdst_solver.c:143 mexFunction
+ *     sims         = egdst_simulator(model,rnd) @egdstmodel/egdstmodel.m:1268  -> egdst_simulator.c:47 mexFunction
+ * Every entry point below is what a MEX (or any FFI) shim for those two gateways binds; the model
+ * plugin (utility, budget, trpr ... compile.m:183-655) is compiled INTO the library as gfx950
+ * device code, exactly as the reference compiles modelspec.c into each MEX file.  Plain pointers
+ * and sizes only; all buffers are caller-owned host memory unless a name ends in _dev.
+ *
+ * Error convention: the reference fills a global err[300] (egdst_lib.c:299-302), returns partial
+ * results and warns (egdst_solver.c:237).  Here every call returns 0 or an EGDST_E_* code, solve
+ * reports a per-draw status, unsolved cells have length 0, egdst_strerror() gives the reference's
+ * message for a code and egdst_last_error() the text of the last failing call of this thread.
+ */
+#ifndef EGDST_H
+#define EGDST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run-time scalars read by parseModel on every call (egdst_lib.c:34-62) plus the quadrature
+ * array built by solve (egdstmodel.m:1157-1160): ny weights followed by ny Gauss-Legendre
+ * abscissae on [0,1]; the library applies the inverse normal cdf itself (egdst_solver.c:164). */
+typedef struct egdst_desc {
+    int t0, T;          /* first and last period; nt = T-t0+1 */
+    int ngridm;         /* standard number of endogenous grid points */
+    int ngridmax;       /* capacity of a cell, rows (without the a0 row) */
+    int nthrhmax;       /* capacity of a threshold list */
+    int ny;             /* quadrature order */
+    double mmax, a0;    /* largest cash-in-hand, credit constraint */
+    const double *quadrature; /* host, [2*ny] */
+} egdst_desc;
+
+/* Constants baked into this model's library (compile-time in the reference too). */
+typedef struct egdst_model_info {
+    int nst, nd, nnst, nnd, nparam, neq, distrib;
+    int optim_MUnoD, optim_UnoD, optim_UasD, optim_TRPRnoSH;
+    double tolerance, zeroconsumption, doublepoint_delta; /* cflags, egdstmodel.m:420-424 */
+    const char *label;
+} egdst_model_info;
+
+typedef struct egdst_handle egdst_handle; /* device-resident batch of independent solves */
+
+enum {
+    EGDST_OK = 0,
+    EGDST_E_ARG = 1,            /* bad argument / descriptor */
+    EGDST_E_HIP = 2,            /* HIP runtime failure (text in egdst_last_error) */
+    EGDST_E_NOGPU = 3,          /* no gfx950 device visible: there is no CPU fallback */
+    /* solver errors; same conditions and texts as the reference's error() calls */
+    EGDST_E_INTERP2 = 10,       /* egdst_lib.c:172 */
+    EGDST_E_TRPR_SUM = 11,      /* egdst_solver.c:580 */
+    EGDST_E_NO_SAVINGS = 12,    /* egdst_solver.c:589 */
+    EGDST_E_GRID_FULL = 13,     /* egdst_solver.c:662,1336,1378,1413,1456,1890,1912 */
+    EGDST_E_EMPTY_CHOICESET = 14, /* egdst_solver.c:700 */
+    EGDST_E_ALL_NEG_INF = 15,   /* egdst_solver.c:707 */
+    EGDST_E_ENVELOPE = 16,      /* egdst_solver.c:726 */
+    EGDST_E_ENV2_SPACE = 17,    /* egdst_solver.c:823,884 */
+    EGDST_E_ENV2_SEGMENTS = 18, /* egdst_solver.c:832 */
+    EGDST_E_ADRAW_INIT = 19,    /* egdst_solver.c:1018 */
+    EGDST_E_THRH_FULL = 20,     /* egdst_solver.c:1327,1891 */
+    EGDST_E_TWO_ANALYTIC = 21,  /* egdst_solver.c:1691 */
+    EGDST_E_BRACKET_OUT = 22,   /* egdst_solver.c:1938 */
+    EGDST_E_BRACKET_REV = 23,   /* egdst_solver.c:1943 */
+    EGDST_E_BUDGET_INVERT = 24, /* egdst_lib.c:293 */
+    EGDST_E_TRPR_CASES = 25,    /* compile.m:541-544 */
+    EGDST_E_RESEND_IN_GRID = 26,/* c1<=0 after the first kept grid point (egdst_solver.c:1080-1099 reached
+                                   from the parallel grid stage): not supported by this build, fails loudly */
+    EGDST_E_INTERNAL = 27,      /* scratch exhausted (crossing stack) */
+    /* simulator gateway (egdst_simulator.c:54-75,155,165) */
+    EGDST_E_NOT_SOLVED = 40,
+    EGDST_E_RAND_SHORT = 41,
+    EGDST_E_SIM_STATE = 42
+};
+
+int egdst_get_model_info(egdst_model_info *out);
+const char *egdst_strerror(int code);
+const char *egdst_last_error(void);
+
+/* Create a batch of `ndraw` independent solves of this model.  keep_history=1 keeps every period's
+ * tables resident (needed for cell export and simulation); 0 keeps two ping-pong periods only.
+ * stream: a hipStream_t (NULL = the library creates its own non-blocking stream). */
+int egdst_create(const egdst_desc *desc, int ndraw, int keep_history, void *stream, egdst_handle **out);
+int egdst_destroy(egdst_handle *h);
+
+/* Parameter vectors, one row per draw: params[draw*nparam + k] (loadparameters, compile.m:469-475).
+ * F8 of SURVEY.md: the batch-of-draws surface is new; ndraw==1 is the reference's setparam+solve. */
+int egdst_set_params(egdst_handle *h, const double *params, int ndraw);
+int egdst_set_params_dev(egdst_handle *h, const double *params_dev, int ndraw);
+
+/* Backward induction for all draws (egdst_solver.c:258-339).  _async only enqueues on the handle's
+ * stream; egdst_sync waits and returns the first non-zero per-draw status (or 0). */
+int egdst_solve_async(egdst_handle *h);
+int egdst_sync(egdst_handle *h);
+int egdst_solve(egdst_handle *h);
+int egdst_get_status(egdst_handle *h, int *status /* [ndraw] */, int *where /* [2*ndraw] (it,ist) or NULL */);
+
+/* EGM evaluations the reference would have executed (body at egdst_solver.c:548-570), summed over draws. */
+int egdst_get_evals(egdst_handle *h, long long *total, long long *per_draw /* [ndraw] or NULL */);
+
+/* Cell export in the reference's wire layout (saveoutput, egdst_solver.c:917-952):
+ *   M cell: (len x 4) column-major [M C A V], row 0 = (a0, 0, a0, evf(a0));  D cell: (thlen x 2) [D TH].
+ * Requires keep_history=1.  len==0: the cell was not solved (infeasible state or earlier error). */
+int egdst_cell_dims(egdst_handle *h, int draw, int it, int ist, int *len, int *thlen);
+int egdst_get_cell_M(egdst_handle *h, int draw, int it, int ist, double *out /* [len*4] */);
+int egdst_get_cell_D(egdst_handle *h, int draw, int it, int ist, double *out /* [thlen*2] */);
+/* Bulk export of one draw: lens/thlens [nt*nst], M/C/V [nt*nst*(ngridmax+1)], D/TH [nt*nst*nthrhmax];
+ * slot = it*nst+ist.  Any pointer may be NULL. */
+int egdst_get_solution(egdst_handle *h, int draw, int *lens, int *thlens, double *M, double *C, double *V,
+                       double *D, double *TH);
+
+/* Forward simulation of draw `draw` (egdst_simulator.c:47-117): init [nsim x 2] column-major (state index
+ * base-1, cash-in-hand), randstream uniforms, rndtype 1 = every agent reuses the head of the stream.
+ * sims: [nsimout x nt x nsim] column-major, nsimout = 11+nnst+nnd+neq, NaN where the agent is dead. */
+int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
+                   long long nrand, int rndtype, double *sims);
+
+/* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
+int egdst_get_debug(egdst_handle *h, int draw, int *out16);
+
+/* Raw device views for callers that keep data resident (bench, estimation loops). */
+int egdst_device_tables(egdst_handle *h, int it, const double **M_dev, const double **C_dev, const double **V_dev,
+                        const int **len_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+// Sanitizer harness ONLY (tests/cpu_emu): a minimal stand-in for <hip/hip_runtime.h> that lets the device
+// code of egdst_amd/csrc be compiled by g++ with -fsanitize=address,undefined and executed with
+// ONE-THREAD workgroups (WAVE=GRID_BS=ENV_BS=1), so barriers and cross-lane operations are trivial.
+// It exists to find out-of-bounds accesses and undefined behaviour in the kernels without risking a
+// GPU fault.  It is never built into, imported by, or reachable from the egdst_amd package.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#ifdef EMU_PARALLEL_BLOCKS
+#define __shared__ static thread_local
+#else
+#define __shared__ static
+#endif
+#define __restrict__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+static thread_local dim3 threadIdx(0, 0, 0);
+static thread_local dim3 blockIdx(0, 0, 0);
+static dim3 blockDim, gridDim;
+
+using std::isfinite;
+using std::max;
+using std::min;
+
+#include <pthread.h>
+#include <thread>
+#include <vector>
+static pthread_barrier_t emu_barrier;
+static int emu_block_threads = 1;
+static inline void __syncthreads()
+{
+    if (emu_block_threads > 1) pthread_barrier_wait(&emu_barrier);
+}
+template <class T> static inline T __shfl(T v, int) { return v; }
+static inline int __any(int x) { return x != 0; }
+static inline int atomicCAS(int *p, int cmp, int val)
+{
+    int old = *p;
+    if (old == cmp) *p = val;
+    return old;
+}
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
+{
+    unsigned long long old = *p;
+    *p += v;
+    return old;
+}
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0 };
+enum { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1 };
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)malloc(n ? n : 1); return *p ? 0 : 1; }
+static inline hipError_t hipFree(void *p) { free(p); return 0; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+
+// Default: workgroups run one after another; the threads of a workgroup run concurrently (std::thread) and
+// meet at a pthread barrier, so ThreadSanitizer sees intra-workgroup races.  With EMU_PARALLEL_BLOCKS (and
+// one-thread workgroups) all workgroups of a launch run concurrently instead: inter-workgroup races.
+#ifdef EMU_PARALLEL_BLOCKS
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                 \
+    do {                                                                            \
+        dim3 g_ = (grid), b_ = (block);                                             \
+        gridDim = g_;                                                               \
+        blockDim = b_;                                                              \
+        emu_block_threads = 1;                                                      \
+        std::vector<std::thread> th_;                                               \
+        for (unsigned by_ = 0; by_ < g_.y; by_++)                                   \
+            for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                               \
+                th_.emplace_back([=]() {                                            \
+                    blockIdx = dim3(bx_, by_, 0);                                   \
+                    threadIdx = dim3(0, 0, 0);                                      \
+                    kernel(__VA_ARGS__);                                            \
+                });                                                                 \
+        for (auto &t_ : th_) t_.join();                                             \
+    } while (0)
+#else
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                 \
+    do {                                                                            \
+        dim3 g_ = (grid), b_ = (block);                                             \
+        gridDim = g_;                                                               \
+        blockDim = b_;                                                              \
+        emu_block_threads = (int)b_.x;                                              \
+        if (b_.x > 1) pthread_barrier_init(&emu_barrier, nullptr, b_.x);            \
+        for (unsigned bz_ = 0; bz_ < g_.z; bz_++)                                   \
+            for (unsigned by_ = 0; by_ < g_.y; by_++)                               \
+                for (unsigned bx_ = 0; bx_ < g_.x; bx_++) {                         \
+                    if (b_.x == 1) {                                                \
+                        blockIdx = dim3(bx_, by_, bz_);                             \
+                        threadIdx = dim3(0, 0, 0);                                  \
+                        kernel(__VA_ARGS__);                                        \
+                    } else {                                                        \
+                        std::vector<std::thread> th_;                               \
+                        for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                   \
+                            th_.emplace_back([=]() {                                \
+                                blockIdx = dim3(bx_, by_, bz_);                     \
+                                threadIdx = dim3(tx_, 0, 0);                        \
+                                kernel(__VA_ARGS__);                                \
+                            });                                                     \
+                        for (auto &t_ : th_) t_.join();                             \
+                    }                                                               \
+                }                                                                   \
+        if (b_.x > 1) pthread_barrier_destroy(&emu_barrier);                        \
+    } while (0)
+#endif
