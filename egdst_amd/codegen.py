@@ -127,6 +127,8 @@ class _Rewriter:
                 return 'E->' + t
             if t in ('nd', 'nnd', 'nst', 'nnst'):
                 return 'MS_' + t.upper()
+            if t in ('exp', 'log', 'pow'):
+                return 'MS_' + t.upper()  # include/egdst_math.h: bit-reproducible or native libm
             if t in _C_KEEP:
                 return t
             raise CodegenError('Unknown identifier `%s` in %s: %s' % (t, where, text))
@@ -201,6 +203,7 @@ def generate_modelspec(model):
     w('#ifndef MS_FN')
     w('#error "define MS_FN (function qualifier) and MS_TABLE (constant-table qualifier) before including modelspec.h"')
     w('#endif')
+    w('#include "egdst_math.h"')
     w('#define MS_LABEL "%s"' % re.sub(r'[^A-Za-z0-9 _.-]', '', m.label))
     w('#define MS_NNST %d' % m.nnst)
     w('#define MS_NND %d' % m.nnd)

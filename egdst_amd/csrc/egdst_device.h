@@ -13,7 +13,7 @@
 
 #define MS_FN static __device__ __forceinline__
 #define MS_TABLE static __device__ const
-#include "modelspec.h"
+#include "modelspec.h"  // pulls in include/egdst_math.h (MS_EXP/MS_LOG/MS_POW)
 
 #define EG_TOL MS_TOLERANCE
 #define EG_ZEROC MS_ZEROCONSUMPTION
@@ -84,12 +84,12 @@ __host__ __device__ inline double eg_inv_normal_cdf(double p)
     if (p == 0) return -HUGE_VAL;
     if (p == 1) return HUGE_VAL;
     if (p < 0.02425) {
-        double q = sqrt(-2 * log(p));
+        double q = sqrt(-2 * MS_LOG(p));
         return (((((c0c * q + c1c) * q + c2c) * q + c3c) * q + c4c) * q + c5c) /
                ((((d0c * q + d1c) * q + d2c) * q + d3c) * q + 1);
     }
     if (p > 0.97575) {
-        double q = sqrt(-2 * log(1 - p));
+        double q = sqrt(-2 * MS_LOG(1 - p));
         return -(((((c0c * q + c1c) * q + c2c) * q + c3c) * q + c4c) * q + c5c) /
                ((((d0c * q + d1c) * q + d2c) * q + d3c) * q + 1);
     }
@@ -102,7 +102,7 @@ __host__ __device__ inline double eg_inv_normal_cdf(double p)
 MS_FN double eg_shock_node(const ms_env *E, const ms_pv *cur, const ms_pv *nxt, double z)
 {
 #if MS_DISTRIB == 1
-    return exp(ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt));
+    return MS_EXP(ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt));
 #else
     return ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt);
 #endif
@@ -110,7 +110,7 @@ MS_FN double eg_shock_node(const ms_env *E, const ms_pv *cur, const ms_pv *nxt, 
 MS_FN double eg_shock_mean(const ms_env *E, const ms_pv *cur, const ms_pv *nxt)
 {
 #if MS_DISTRIB == 1
-    return exp(ms_mu(E, cur, nxt) + ms_sigma(E, cur, nxt) * ms_sigma(E, cur, nxt) / 2);
+    return MS_EXP(ms_mu(E, cur, nxt) + ms_sigma(E, cur, nxt) * ms_sigma(E, cur, nxt) / 2);
 #else
     return ms_mu(E, cur, nxt);
 #endif
@@ -118,7 +118,7 @@ MS_FN double eg_shock_mean(const ms_env *E, const ms_pv *cur, const ms_pv *nxt)
 MS_FN double eg_shock_uniform(double u, double mu, double sigma)
 {
 #if MS_DISTRIB == 1
-    return exp(sigma * eg_inv_normal_cdf(u) + mu);
+    return MS_EXP(sigma * eg_inv_normal_cdf(u) + mu);
 #else
     return sigma * eg_inv_normal_cdf(u) + mu;
 #endif

@@ -11,14 +11,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def build(spec_dir, out=None, opt='-O2'):
-    out = out or os.path.join(spec_dir, 'liboracle.so')
+def build(spec_dir, out=None, opt='-O2', native_math=True):
+    """native_math=True: glibc exp/log/pow like the reference; False: include/egdst_math.h (bit-reproducible)."""
+    out = out or os.path.join(spec_dir, 'liboracle_%s.so' % ('native' if native_math else 'portable'))
     src = os.path.join(HERE, 'egdst_oracle.c')
     spec = os.path.join(spec_dir, 'modelspec.h')
-    if (os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(spec))):
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    if (os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(spec),
+                                                                os.path.getmtime(os.path.join(inc, 'egdst_math.h')))):
         return out
     cmd = ['gcc', opt, '-ffp-contract=off', '-std=gnu99', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
-           '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-I', spec_dir, src, '-o', out, '-lm']
+           '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-I', spec_dir, '-I', inc] + (['-DEGDST_NATIVE_MATH'] if native_math else []) + [src, '-o', out, '-lm']
     subprocess.run(cmd, check=True)
     return out
 

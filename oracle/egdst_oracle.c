@@ -22,7 +22,11 @@
  * although it is only assigned when keep==1 (egdst_solver.c:382,495,572,577,583).  Here evf is
  * 0.0 at the start of every A-guess, which is what the survey's working builds amount to.
  *
- * Build: gcc -O2 -ffp-contract=off -fPIC -shared -I<dir of modelspec.h> egdst_oracle.c -lm
+ * Math: built with -DEGDST_NATIVE_MATH the transcendental functions are glibc's, as in the reference (this is
+ * the build that is pinned to the reference's recorded outputs); without it they are the bit-reproducible
+ * ones of include/egdst_math.h, which the GPU path uses too, so GPU and oracle can be compared bit for bit.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared [-DEGDST_NATIVE_MATH] -I<dir of modelspec.h> -I include egdst_oracle.c -lm
  */
 #include <math.h>
 #include <stdio.h>
@@ -74,12 +78,12 @@ static double inv_normal_cdf(double p)
     if (p == 0) return -HUGE_VAL;
     if (p == 1) return HUGE_VAL;
     if (p < 0.02425) {
-        q = sqrt(-2 * log(p));
+        q = sqrt(-2 * MS_LOG(p));
         return (((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) /
                ((((cd[0] * q + cd[1]) * q + cd[2]) * q + cd[3]) * q + 1);
     }
     if (p > 0.97575) {
-        q = sqrt(-2 * log(1 - p));
+        q = sqrt(-2 * MS_LOG(1 - p));
         return -(((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) /
                ((((cd[0] * q + cd[1]) * q + cd[2]) * q + cd[3]) * q + 1);
     }
@@ -94,7 +98,7 @@ static double inv_normal_cdf(double p)
 static double shock_from_node(const ms_env *E, const ms_pv *cur, const ms_pv *nxt, double z)
 {
 #if MS_DISTRIB == 1
-    return exp(ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt));
+    return MS_EXP(ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt));
 #else
     return ms_mu(E, cur, nxt) + z * ms_sigma(E, cur, nxt);
 #endif
@@ -102,7 +106,7 @@ static double shock_from_node(const ms_env *E, const ms_pv *cur, const ms_pv *nx
 static double shock_expectation(const ms_env *E, const ms_pv *cur, const ms_pv *nxt)
 {
 #if MS_DISTRIB == 1
-    return exp(ms_mu(E, cur, nxt) + ms_sigma(E, cur, nxt) * ms_sigma(E, cur, nxt) / 2);
+    return MS_EXP(ms_mu(E, cur, nxt) + ms_sigma(E, cur, nxt) * ms_sigma(E, cur, nxt) / 2);
 #else
     return ms_mu(E, cur, nxt);
 #endif
@@ -110,7 +114,7 @@ static double shock_expectation(const ms_env *E, const ms_pv *cur, const ms_pv *
 static double shock_from_uniform(double u, double mu, double sigma)
 {
 #if MS_DISTRIB == 1
-    return exp(sigma * inv_normal_cdf(u) + mu);
+    return MS_EXP(sigma * inv_normal_cdf(u) + mu);
 #else
     return sigma * inv_normal_cdf(u) + mu;
 #endif

@@ -17,7 +17,7 @@ def build(spec_dir, sanitize=True, env_bs=1, parallel_blocks=False):
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
         return out
     cmd = ['g++', '-x', 'c++', '-std=c++17', '-O1', '-g', '-ffp-contract=off', '-fPIC', '-shared',
-           '-DWAVE=1', '-DGRID_BS=1', '-DENV_BS=%d' % env_bs, '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC,
+           '-DWAVE=1', '-DGRID_BS=1', '-DENV_BS=%d' % env_bs, '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
            '-Wno-unused-function', os.path.join(CSRC, 'egdst_kernels.hip'), '-o', out]
     if parallel_blocks:
         cmd[1:1] = ['-DEMU_PARALLEL_BLOCKS']

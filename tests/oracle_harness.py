@@ -59,7 +59,9 @@ class OracleSolution:
 
 
 class Oracle:
-    def __init__(self, model, build_dir=None):
+    def __init__(self, model, build_dir=None, native_math=False):
+        """native_math=True reproduces the reference's glibc arithmetic (known-answer tests); the default uses
+        the bit-reproducible functions of include/egdst_math.h, exactly as the GPU path does."""
         text = codegen.generate_modelspec(model)
         tag = ''.join(ch for ch in model.label if ch.isalnum())[:16] + '_' + codegen.spec_hash(text)
         d = build_dir or os.path.join(ROOT, 'oracle', '_build', tag)
@@ -68,7 +70,7 @@ class Oracle:
         if not os.path.exists(spec) or open(spec).read() != text:
             with open(spec, 'w') as f:
                 f.write(text)
-        self.lib = C.CDLL(build_oracle.build(d))
+        self.lib = C.CDLL(build_oracle.build(d, native_math=native_math))
         self.model = model
         self.lib.egdst_oracle_solve.restype = C.c_int
         self.lib.egdst_oracle_sim.restype = C.c_int

@@ -27,7 +27,7 @@ def close(a, b):
 @pytest.fixture(scope='module', params=['retirement2', 'deaton2', 'retirement1', 'deaton1', 'occ3'])
 def solved(request):
     m = examples.REGISTRY[request.param]()
-    sol = Oracle(m).solve()
+    sol = Oracle(m, native_math=True).solve()  # glibc arithmetic, as the reference
     assert sol.rc == 0, sol.err
     return request.param, sol
 
