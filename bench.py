@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- EGM grid-point x shock evals/s of the batched backward induction on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full backward induction (terminal period + T-t0 EGM periods, envelopes included) of a
+batch of `--ndraw` independent parameter draws of the workload, inputs (parameter vectors, quadrature)
+resident in HBM when the timed region starts.  Weak scaling: every rank solves `--ndraw` draws of its own
+(draws are independent); the only collective is the RCCL all-reduce of the per-draw
+objective contributions after the timed steps.  Rank 0 prints ONE JSON line.
+
+value       = evals the REFERENCE would execute for these draws (counted on device, equal to the oracle's
+              count in the parity tests) * ranks / max-over-ranks wall time
+roofline    = algorithmic table bytes per launch of the dominant kernel / its mean HIP-event duration,
+              against the 8 TB/s HBM3E peak (the path is NOT bandwidth bound at these sizes,
+              the fraction is reported honestly)
+cpu_baseline= the CPU oracle (oracle/egdst_oracle.c, glibc math, gcc -O2, 1 thread) on a bounded sample
+              of the same draws, timed in this run on the GPU box's host
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(model, draws, budget_s=12.0):
+    """Single-thread oracle (the 'port' of the reference CPU path) on a bounded sample of the draws."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle_harness import Oracle
+    orc = Oracle(model, native_math=True)
+    t0 = time.perf_counter()
+    evals, n = 0, 0
+    for p in draws:
+        sol = orc.solve(p)
+        evals += sol.nevals
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': evals / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d draws of the same workload, %.1f s, oracle/egdst_oracle.c gcc -O2 glibc math' % (n, dt),
+            'wall_s_per_solve': dt / max(n, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='C2')
+    ap.add_argument('--ndraw', type=int, default=256, help='parameter draws per GPU (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from egdst_amd import build, runtime, workloads
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the egdst hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    model, drawgen = workloads.WORKLOADS[args.workload]()
+    lib = build.build_model(model)  # prebuilt in-tree by __graft_entry__.build(); rebuilds if stale
+    desc = model.descriptor()
+    ndraw = args.ndraw
+    all_draws = drawgen(ndraw * world) if drawgen else np.tile(model.param_vector(), (ndraw * world, 1))
+    mine = np.ascontiguousarray(all_draws[rank * ndraw:(rank + 1) * ndraw])
+
+    stream = torch.cuda.Stream()
+    solver = runtime.Solver(lib, desc, ndraw=ndraw, keep_history=False, stream=stream.cuda_stream)
+    params_dev = torch.from_numpy(mine).cuda()          # inputs resident in HBM before the timed region
+    obj = torch.zeros(ndraw, 2, dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    solver.set_params_dev(params_dev.data_ptr())
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve_async()
+    solver.sync(raise_on_error=False)
+    solver.set_profile(True)
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve_async()
+    solver.sync(raise_on_error=False)
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    status, _ = solver.status()
+    evals_step, _ = solver.evals()
+    kms, klaunch, algbytes = solver.profile()       # of the LAST step (events are re-recorded every step)
+    # final objective reduce (the only collective of the path, RCCL over xGMI when world > 1)
+    with torch.cuda.stream(stream):
+        solver.objective_dev(obj.data_ptr())
+    stream.synchronize()
+    okmask = ~torch.isnan(obj[:, 0])
+    red = torch.stack([torch.where(okmask, obj[:, 0], torch.zeros_like(obj[:, 0])).sum(), okmask.sum().double()])
+    tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    ev = torch.tensor([float(evals_step)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+    dt_max = float(tt.item())
+    evals_all = float(ev.item())
+
+    if rank == 0:
+        ms_step = dt_max / args.steps * 1e3
+        names = ['probe', 'grid', 'envelope']
+        dom = int(np.argmax(kms))
+        avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
+        bytes_per_launch = algbytes / max(klaunch[dom], 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # single-solve latency (one draw) for the "full backward-induction wall time" half of the metric
+        s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
+        s1.set_params(mine[:1])
+        s1.solve()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            s1.solve()
+        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+        s1.close()
+        out = {
+            'metric': 'EGM grid-point x shock evals/sec (batched backward induction, all draws, all periods)',
+            'value': evals_all / (dt_max / args.steps), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: %s, T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (
+                args.workload, model.label, desc['T'], desc['ngridm'], desc['ny'], lib.info.nd, lib.info.nst,
+                desc['a0'], desc['mmax']), 'ndraw_per_gpu': ndraw, 'ndraw_total': ndraw * world,
+                'parallelism': 'draws sharded over %d rank(s), no data-path collective' % world},
+            'evals_per_step': evals_all, 'failed_draws_rank0': int((status != 0).sum()),
+            'single_solve_ms': single_ms,
+            'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
+            'kernel_ms_per_step': {n: float(v) for n, v in zip(names, kms)},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_' + names[dom], 'achieved': achieved, 'peak': 8000.0,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None,
+                         'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
+                         'launches': int(klaunch[dom])},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, mine)
+            out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']
+            out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / single_ms
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -54,10 +54,13 @@ struct Batch {
     int *where;           // [2*ndraw] (it, ist) of that error
     unsigned long long *evals;  // [ndraw]
     int *dbg;             // [16*ndraw] diagnostics of a tripped internal guard
+    unsigned long long *algbytes;  // [ndraw] compulsory table traffic: 24 B per next-period row read once per
+                                   // period + 24 B per row written + 16 B per threshold
 };
 
 struct ProbeOut {
     int active;       // choice is in the choice set (and the state feasible)
+    int seq;          // 1: the whole stream was generated sequentially by k_fixup (candidates 0..np-1, all kept)
     int np;           // 1 if the probe stored a kept point at candidate index 0
     int grid;         // 1 if the guess generator entered the grid stage (points n>=1 may be requested)
     int ncalls;       // calls made before the first grid point (for the runaway guard, egdst_solver.c:963)

@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
     const int act = ms_feasible(&E, &cur) == 1 && ms_inchoiceset(&E, &cur) == 1;
     if (i == 0) {
         P->active = act;
+        P->seq = 0;
         P->np = 0;
         P->grid = 0;
         P->probe_evals = 0;
@@ -178,14 +179,16 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
     return status;
 }
 
-// Head of the guess generator (adraw, egdst_solver.c:955-1099) up to the call that would emit the
-// first point of the closed-form grid.  One wave per (draw, ist, id); all lanes carry the same state.
-__global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
+// The guess generator (adraw, egdst_solver.c:955-1159) run by one wave for one (draw, ist, id); all lanes carry
+// the same state and every expectation is evaluated cooperatively (eg_wave_expectation).
+//   full == 0 (k_probe): stop at the call that would emit the first point of the closed-form grid and hand the
+//            limits over to k_grid, which evaluates the remaining points in parallel;
+//   full == 1 (k_fixup): keep going point by point to the end of the stream.  This is the exact sequential
+//            algorithm; it is used when a zero-consumption resend turns up INSIDE the grid stage
+//            (egdst_solver.c:1080-1099), which re-bases every later guess and cannot be speculated in parallel.
+static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, int draw, int ist, int id, int full)
 {
-    const int combo = blockIdx.x;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
-    if (b.status[draw]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     ms_env E = eg_env(b, draw);
     ms_pv cur;
     cur.it = it;
@@ -258,11 +261,23 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
                 lim1 = ms_tr(&E, &cur, lim3p - a0);
                 lim2 = ms_tr(&E, &cur, lim2p - lim3p);
                 lim3 = ms_tr(&E, &cur, 0);
-            } else {
+            } else if (!full) {
                 // the next call either starts the closed-form grid (handled by k_grid) or ends the stream
                 grid = (M < mmax && ngenerated < ntogenerate) ? 1 : 0;
                 break;
-            }
+            } else if (M < mmax && ngenerated < ntogenerate) {  // next point of the log grid (:1100-1149)
+                ncalls += 1;
+                keep = 1;
+                double step;
+                if (ngenerated < (int)k3 - 1)
+                    step = -ms_trinv(&E, &cur, lim3 + (k3 - 1 - ngenerated) * (lim1 - lim3) / (k3 - 1)) + lim3p - last;
+                else
+                    step = ms_trinv(&E, &cur, lim3 + (ngenerated - k3 + 1) * (lim2 - lim3) / (ntogenerate - k3)) + lim3p - last;
+                if (step < 0) step = MS_MAX(step, 1e-5);
+                last += step;
+                ngenerated += 1;
+            } else
+                break;  // stream ends (:1150-1152)
         }
         // ---- evaluate the guess -----------------------------------------------------------
         double rhs, evf;
@@ -303,17 +318,22 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
         M = last + ms_utility_marginal_inverse(&E, &cur, rhs);
         if (keep == 1 && isfinite(M)) {
             if (fabs(last - a0) < EG_TOL && evfa0 > -INFINITY) evfa0 = evf;
+            if (np >= b.g.ngridmax - 1) {  // (:662)
+                if (lane == 0) eg_fail(b, draw, it, ist, 13);
+                return;
+            }
             if (lane == 0) {
                 const double c = M - last;
-                b.cM[co] = M;
-                b.cC[co] = c;
-                b.cV[co] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+                b.cM[co + np] = M;
+                b.cC[co + np] = c;
+                b.cV[co + np] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
             }
-            np += 1;  // at most one kept point can precede the grid stage
+            np += 1;  // full == 0: at most one kept point can precede the grid stage
         }
     }
     if (lane == 0) {
         P->active = 1;
+        P->seq = full;
         P->np = np;
         P->grid = grid;
         P->ncalls = ncalls;
@@ -328,6 +348,45 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
         P->M0 = M;
         P->evfa0 = evfa0;
     }
+}
+
+__global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
+{
+    const int combo = blockIdx.x;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    if (b.status[draw]) return;
+    eg_adraw_cycle(b, it, draw, ist, id, 0);
+}
+
+// After k_grid: does the stream of (draw, ist, id) contain a zero-consumption signal among the points the
+// generator would actually request?  If so redo that stream sequentially (exactly as the reference does).
+__global__ void __launch_bounds__(WAVE) k_fixup(Batch b, int it)
+{
+    const int combo = blockIdx.x;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    if (b.status[draw]) return;
+    const int lane = threadIdx.x;
+    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    if (!P.active || !P.grid) return;
+    const size_t co = eg_cand(b, draw, ist, id);
+    const int navail = min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls);
+    int resend = 0;
+    for (int base = 1; base <= navail; base += WAVE) {  // in stream order, 64 points at a time
+        const int n = base + lane;
+        int stop = 0, neg = 0;
+        if (n <= navail) {
+            stop = !(b.cR[co + n] < b.g.mmax);
+            neg = (b.cSt[co + n] == 1);
+        }
+        const unsigned long long ms = __ballot(stop), mn = __ballot(neg);
+        if (mn) {
+            const int fneg = __ffsll((long long)mn) - 1, fstop = ms ? __ffsll((long long)ms) - 1 : WAVE;
+            if (fneg <= fstop) resend = 1;  // a stopping point is itself still requested
+        }
+        if (resend || ms) break;
+    }
+    if (!resend) return;
+    eg_adraw_cycle(b, it, draw, ist, id, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,9 +610,25 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         of[r] = f;
     }
     __syncthreads();
+    // rank[fstart[f]+k] must be the sorted position of the k-th point of f IN SORTED ORDER (the reference builds
+    // its per-function lists from the sorted array, egdst_solver.c:1247-1255).  That is what the merge produced
+    // when every list was already ordered; after the counting fallback the lists are rebuilt from the sorted
+    // stream (sequential, rare: a list is only out of order when a kink's double point overtakes a grid point).
+    if (bad) {
+        if (threadIdx.x == 0) {
+            // `rank` is not needed as a permutation any more: overwrite it with the per-function position lists
+            for (int g = 0; g < nf; g++) {
+                if (dims[g] <= 0) continue;
+                int c = 0;
+                for (int r = 0; r < npts; r++)
+                    if (of[r] == g) rank[fstart[g] + c++] = r;
+            }
+        }
+        __syncthreads();
+    }
 #ifdef EGDST_VERIFY_SORT
     // diagnostic build: the output must be a permutation of the input in comp1 order
-    for (int i = threadIdx.x; i < npts; i += ENV_BS) {
+    for (int i = threadIdx.x; i < npts && !bad; i += ENV_BS) {
         int r = rank[i];
         bool okp = (of[r] == ifn[i]) && (om[r] == im[i] || (om[r] != om[r] && im[i] != im[i]));
         bool oks = (i == 0) || pt_before(om[i - 1], ov[i - 1], of[i - 1], 0, om[i], ov[i], of[i], 1);
@@ -642,6 +717,9 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         double evfa0 = P.evfa0;
         if (terminal) {
             nreq = ngridm - 1;  // candidate indices 0..ngridm-1, all kept
+        } else if (P.seq) {
+            nreq = P.np - 1;    // k_fixup stored the kept points of the whole stream in order
+            evals += (unsigned long long)P.probe_evals;
         } else {
             const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
             // first requested point whose returned M stops the stream (:1100): the point itself is kept
@@ -678,7 +756,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                 const int n = base + tid;
                 int keepit = 0;
                 if (n <= nreq) {
-                    if (terminal)
+                    if (terminal || P.seq)
                         keepit = 1;
                     else if (n == 0)
                         keepit = P.np;
@@ -912,6 +990,16 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         b.tlen[tk] = outn + 1;
         b.tthlen[tk] = outm;
         if (evals) atomicAdd(&b.evals[draw], evals);
+        {   // algorithmic bytes of this cell: its rows written once (M, C, V; A = M - C is derived on export) and,
+            // for the EGM periods, the next-period table of the same state index read once
+            unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull * (unsigned long long)outm;
+            if (!terminal) {
+                const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+                const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
+                by += 24ull * (unsigned long long)b.tlen[k1] + 16ull * (unsigned long long)b.tthlen[k1];
+            }
+            atomicAdd(&b.algbytes[draw], by);
+        }
     }
 }
 
@@ -1025,6 +1113,19 @@ __global__ void k_fill_nan(double *p, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (i == 0) ? 0.0 : NAN;  // NaN fill starts at element 1 (egdst_simulator.c:105)
+}
+
+// Per-draw objective contribution for an estimation loop (new surface): the value and the
+// consumption at the first endogenous grid point of (it=0, ist=0); NaN when the draw failed.
+__global__ void k_objective(Batch b, double *out)
+{
+    const int draw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (draw >= b.g.ndraw) return;
+    const int slot = (b.g.nslots == 2) ? 0 : 0;
+    const size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST;
+    const bool ok = b.status[draw] == 0 && b.tlen[k] >= 2;
+    out[2 * draw] = ok ? b.tV[k * b.g.S + 1] : NAN;
+    out[2 * draw + 1] = ok ? b.tC[k * b.g.S + 1] : NAN;
 }
 
 #include "egdst_host.inc"

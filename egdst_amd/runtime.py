@@ -29,7 +29,8 @@ class EgdstModelInfo(C.Structure):
 ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'egdst_create', 'egdst_destroy',
                'egdst_set_params', 'egdst_set_params_dev', 'egdst_solve_async', 'egdst_sync', 'egdst_solve',
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
-               'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug']
+               'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
+               'egdst_get_profile', 'egdst_objective_dev']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -76,6 +77,9 @@ class ModelLibrary:
         L.egdst_simulate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
                                      C.c_longlong, C.c_int, C.POINTER(C.c_double)]
         L.egdst_get_debug.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.egdst_objective_dev.argtypes = [C.c_void_p, C.c_void_p]
+        L.egdst_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.egdst_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
         L.egdst_device_tables.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4
         info = EgdstModelInfo()
         L.egdst_get_model_info(C.byref(info))
@@ -192,6 +196,20 @@ class Solver:
         sol.err = self.lib.lib.egdst_strerror(sol.status).decode() if sol.status else ''
         sol.nevals = int(self.evals()[1][draw])
         return sol
+
+    def objective_dev(self, dev_ptr):
+        self.lib.check(self.lib.lib.egdst_objective_dev(self.h, C.c_void_p(dev_ptr)))
+
+    def set_profile(self, on=True):
+        self.lib.check(self.lib.lib.egdst_set_profile(self.h, int(on)))
+
+    def profile(self):
+        """(ms[3], launches[3], algorithmic bytes) of the last solve: kernels probe/terminal, grid, envelope."""
+        ms = np.zeros(3)
+        ln = np.zeros(3, dtype=np.int32)
+        ab = C.c_longlong(0)
+        self.lib.check(self.lib.lib.egdst_get_profile(self.h, _dp(ms), _ip(ln), C.byref(ab)))
+        return ms, ln, int(ab.value)
 
     def debug(self, draw=0):
         out = np.zeros(16, dtype=np.int32)

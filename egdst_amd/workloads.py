@@ -1,0 +1,62 @@
+"""BASELINE.json configs restated concretely + parameter-draw generators.
+
+C2 note: with the shipped credit limit a0=-5 the reference algorithm itself emits a non-finite
+consumption row at it=4 for T=60/ngridm=1000 (checked with the glibc oracle), so the T=60 config
+uses a0=0, for which every period is finite and monotone; the a0=-5 forms are covered at T=40.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import examples
+
+
+def _draws(seed, ndraw, lo, hi):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    return lo + (hi - lo) * rng.random((ndraw, len(lo)))
+
+
+def c1():
+    return examples.deaton_sig(a0=0, mmax=50, t0=1, T=20, ngridm=100, ny=5), None
+
+
+def c2(ngridm=1000, T=60, ny=10):
+    """retirement2 forms, 2 discrete choices, T=60, 1000 grid points, 10 nodes (BASELINE configs[1])."""
+    m = examples.retirement_sig(T=T, ngridm=ngridm, ngridmax=10 * ngridm, nthrhmax=ngridm, ny=ny, a0=0)
+
+    def draws(ndraw, seed=20241):
+        # params: duw, interest, wage, sig  -- draws over (duw, wage, sigma), interest fixed (SURVEY §8d C5 ranges)
+        d = _draws(seed, ndraw, [0.3, 0.9, 0.15], [0.8, 1.3, 0.35])
+        out = np.tile(m.param_vector(), (ndraw, 1))
+        out[:, 0], out[:, 2], out[:, 3] = d[:, 0], d[:, 1], d[:, 2]
+        return out
+    return m, draws
+
+
+def c3():
+    return examples.occ3(ngridm=4000, ngridmax=40000, nthrhmax=4000, ny=15), None
+
+
+def c4(ngridm=65536, T=80, ny=21):
+    """Deaton stress: draws over (interest, income, sigma), rng(20240)."""
+    m = examples.deaton_sig(a0=0, mmax=50, t0=1, T=T, ngridm=ngridm, ngridmax=2 * ngridm, nthrhmax=10, ny=ny)
+
+    def draws(ndraw, seed=20240):
+        return _draws(seed, ndraw, [0.005, 1.0, 0.5], [0.03, 1.5, 0.9])  # interest, income, sig
+    return m, draws
+
+
+def c5(ngridm=32768, T=100, ny=15):
+    m = examples.retirement8(T=T, ngridm=ngridm, ny=ny)
+    m.ngridmax = 4 * ngridm
+
+    def draws(ndraw, seed=20241):
+        d = _draws(seed, ndraw, [0.3, 0.9, 0.15], [0.8, 1.3, 0.35])  # duw, wage, sigma
+        out = np.tile(m.param_vector(), (ndraw, 1))  # duw, interest, wage, sig
+        out[:, 0], out[:, 2], out[:, 3] = d[:, 0], d[:, 1], d[:, 2]
+        return out
+    return m, draws
+
+
+WORKLOADS = {'C1': c1, 'C2': c2, 'C3': c3, 'C4': c4, 'C5': c5}

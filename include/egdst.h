@@ -117,6 +117,19 @@ int egdst_get_solution(egdst_handle *h, int draw, int *lens, int *thlens, double
 int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
                    long long nrand, int rndtype, double *sims);
 
+/* Objective contributions of an estimation loop (new surface): out_dev[2*draw+{0,1}] =
+ * value and consumption at the first endogenous grid point of (it=0, ist=0); NaN for failed draws.  The buffer
+ * is device memory (e.g. a torch tensor) so that the cross-GPU reduce (RCCL) needs no host copy.  Enqueued on
+ * the handle's stream. */
+int egdst_objective_dev(egdst_handle *h, double *out_dev);
+
+/* Measurement: with profiling on, every kernel launch of a solve is bracketed by HIP events on
+ * the handle's stream.  egdst_get_profile returns, for {0: probe/terminal, 1: grid, 2: envelope}, the summed
+ * device time in ms and the number of launches of the LAST solve, and the algorithmic table bytes of that solve
+ * summed over draws (24 B per table row read once per period, 24 B per row written, 16 B per threshold). */
+int egdst_set_profile(egdst_handle *h, int on);
+int egdst_get_profile(egdst_handle *h, double *ms /* [3] */, int *launches /* [3] */, long long *algbytes);
+
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);
 

@@ -46,6 +46,8 @@ static inline void __syncthreads()
 }
 template <class T> static inline T __shfl(T v, int) { return v; }
 static inline int __any(int x) { return x != 0; }
+static inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int atomicCAS(int *p, int cmp, int val)
 {
     int old = *p;
@@ -70,6 +72,11 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = nu
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
+typedef void *hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)malloc(n ? n : 1); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
