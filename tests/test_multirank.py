@@ -1,0 +1,74 @@
+"""N>1 path on CPU: two gloo ranks shard the draws, 'solve' them with the CPU oracle as a stand-in for the
+device solve (the sharding/reduce plumbing is what is under test), and reduce the objective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from egdst_amd import parallel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_bounds_cover_all_draws():
+    for nd in (1, 7, 16, 1024):
+        for w in (1, 2, 3, 8):
+            b = [parallel.shard_bounds(nd, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == nd
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, ndraw, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from egdst_amd import workloads
+    from oracle_harness import Oracle
+    m, gen = workloads.c2(ngridm=40, T=6, ny=3)
+    P = gen(ndraw)
+    lo, hi = parallel.shard_bounds(ndraw, world, rank)
+    orc = Oracle(m)
+    vals = []
+    for p in P[lo:hi]:
+        s = orc.solve(p)
+        vals.append(s.V[0, 0, 1] if s.rc == 0 else float('nan'))
+    local = torch.tensor(vals, dtype=torch.float64)
+    tot, cnt = parallel.reduce_objective(local)
+    allv = parallel.gather_draw_results(local, ndraw)
+    if rank == 0:
+        q.put((tot, cnt, allv.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reduce_equals_single_process():
+    sys.path.insert(0, HERE)
+    from egdst_amd import workloads
+    from oracle_harness import Oracle
+    ndraw = 5
+    m, gen = workloads.c2(ngridm=40, T=6, ny=3)
+    orc = Oracle(m)
+    ref = np.array([orc.solve(p).V[0, 0, 1] for p in gen(ndraw)])
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ndraw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    tot, cnt, allv = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert cnt == ndraw and abs(tot - ref.sum()) <= 1e-12 * abs(ref.sum())
+    assert np.array_equal(allv, ref)
