@@ -22,15 +22,15 @@ def _apply(m, over):
     return m
 
 
-def _deaton(label, sigma, mu, a0, mmax, ny, **over):
+def _deaton(label, sigma, mu, a0_, mmax_, ny_, **over):
     m = egdstmodel(label)
     m.t0 = 1
     m.T = 25
-    m.mmax = mmax
+    m.mmax = mmax_
     m.ngridmax = 1000
     m.ngridm = 100
     m.nthrhmax = 10
-    m.ny = ny
+    m.ny = ny_
     m.s = ('Singleton state', [0, 'dummy state'])
     m.trpr = ('true', [[1]])
     m.feasible = ('defaultfeasible', True)
@@ -46,7 +46,7 @@ def _deaton(label, sigma, mu, a0, mmax, ny, **over):
     m.param = ('interest', 'return on savings', 0.01)
     m.eq = ('income_level', 'Realized income', 'income*shock', 'next')
     m.param = ('income', 'income (times multiplicator shock)', 1.25)
-    m.a0 = a0
+    m.a0 = a0_
     m.shock = 'lognormal'
     m.shock = ('sigma', sigma)
     m.shock = ('mu', mu)
