@@ -8,6 +8,10 @@
 #pragma once
 #include "egdst_device.h"
 
+#ifndef EG_WAVE
+#define EG_WAVE 64
+#endif
+
 struct EnvCtx {
     const ms_env *E;
     int it, ist, nf;
@@ -23,6 +27,8 @@ struct EnvCtx {
     double *og, *ov, *oc, *oth, *oix;
     int oi, oj, ngridmax, nthrhmax;
     int cap, npts;  // capacity of rank[] and number of sorted points (bounds guard)
+    double bound;   // min over functions of the last grid point
+    int ci;         // the reference's `ci` (persists across iterations)
     int *dbg;       // [16] diagnostics of a tripped guard
     int err;
 };
@@ -256,10 +262,11 @@ static __device__ __forceinline__ void env_push(EnvCtx &e, double g, double v, d
     e.oi++;
 }
 
-// The merge walk (:1262-1550).  dims[] must hold the number of points per function, npts their sum.
-static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
+// ---- the merge walk (:1262-1550) ------------------------------------------------------------------------
+// env_begin: state before the first point; env_step: one iteration of the reference's while loop for the
+// sorted position i (returns false when the walk must stop).  dims[] must hold the points per function.
+static __device__ __forceinline__ void env_begin(EnvCtx &e)
 {
-    const double a0 = e.E->a0;
     for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
     double bound = INFINITY;  // min over functions of the last grid point (:1266-1271)
     for (int f = 0; f < e.nf; f++)
@@ -267,115 +274,288 @@ static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
             double last = e.m[env_at(e, f, e.dims[f] - 1)];
             if (last < bound) bound = last;
         }
+    e.bound = bound;
     e.oi = e.oj = 0;
-    int ci = 0;
-    for (int i = 0; i < npts && e.m[i] <= bound && !e.err; i++) {
-        const int f = e.f[i];
-        const double x = e.m[i];
-        if (f < 0 || f >= e.nf || e.dims[f] <= 0) {  // sorted stream inconsistent with the per-function lists
-            if (e.dbg && atomicCAS(&e.dbg[0], 0, 2708) == 0)
-                e.dbg[1] = f, e.dbg[2] = i, e.dbg[3] = e.npts, e.dbg[4] = e.nf, e.dbg[5] = e.sec_id, e.dbg[6] = e.ist;
-            e.err = 2708;
-            return;
+    e.ci = 0;
+}
+
+static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
+{
+    const double a0 = e.E->a0, bound = e.bound;
+    const int f = e.f[i];
+    const double x = e.m[i];
+    if (f < 0 || f >= e.nf || e.dims[f] <= 0) {  // sorted stream inconsistent with the per-function lists
+        if (e.dbg && atomicCAS(&e.dbg[0], 0, 2708) == 0)
+            e.dbg[1] = f, e.dbg[2] = i, e.dbg[3] = e.npts, e.dbg[4] = e.nf, e.dbg[5] = e.sec_id, e.dbg[6] = e.ist;
+        e.err = 2708;
+        return false;
+    }
+    if (e.oi > 0 && e.og[e.oi - 1] == x) {  // duplicate grid point (:1290-1298)
+        e.cur[f]++;
+        return true;
+    }
+    const int self = env_at(e, f, e.cur[f] + 1);
+    double fv = e.v[self];
+    if (e.oj == 0) {  // first point of the common grid (:1303-1347)
+        double t = fv;
+        e.ci = f;
+        for (int j = 0; j < e.nf; j++) {
+            if (e.dims[j] <= 0 || j == f) continue;
+            fv = env_fn(e, j, x);
+            if (fv > t) t = fv, e.ci = j;
+            if (fv == t && e.ci > j) e.ci = j;
         }
-        if (e.oi > 0 && e.og[e.oi - 1] == x) {  // duplicate grid point (:1290-1298)
-            e.cur[f]++;
-            continue;
+        e.oth[e.oj] = a0;
+        e.oix[e.oj] = e.ci;
+        e.oj++;
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return false;
         }
-        const int self = env_at(e, f, e.cur[f] + 1);
-        double fv = e.v[self];
-        if (e.oj == 0) {  // first point of the common grid (:1303-1347)
-            double t = fv;
-            ci = f;
-            for (int j = 0; j < e.nf; j++) {
-                if (e.dims[j] <= 0 || j == f) continue;
-                fv = env_fn(e, j, x);
-                if (fv > t) t = fv, ci = j;
-                if (fv == t && ci > j) ci = j;
+        if (e.ci == f) {
+            env_push(e, x, t, e.c[self]);
+            if (e.oi >= e.ngridmax) {
+                e.err = 13;
+                return false;
             }
-            e.oth[e.oj] = a0;
-            e.oix[e.oj] = ci;
-            e.oj++;
-            if (e.oj >= e.nthrhmax) {
-                e.err = 20;
+        }
+    } else if ((int)e.oix[e.oj - 1] == f) {  // point of the current max function (:1348-1416)
+        int above = 0, j;
+        double t;
+        for (j = 0; j < e.nf; j++) {
+            if (e.dims[j] <= 0 || j == f) continue;
+            t = env_fn(e, j, x);
+            if (fv < t) {
+                above = 1;
+                if (x != bound) break;
+                fv = t;
+                e.ci = j;
+            }
+        }
+        if (!above) {
+            env_push(e, x, fv, e.c[self]);
+            if (e.oi == e.ngridmax) {
+                e.err = 13;
+                return false;
+            }
+        } else if (x != bound) {
+            env_reset_marks(e);
+            env_crossing(e, f, j, 0);
+            if (e.err) return false;
+        } else {
+            env_reset_marks(e);
+            env_crossing(e, f, e.ci, 1);
+            if (e.err) return false;
+            e.og[e.oi] = x;
+            e.ov[e.oi] = env_fn(e, e.ci, x);
+            // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
+            e.oc[e.oi] = (e.cur[e.ci] >= 0) ? env_seg(e, e.ci, e.cur[e.ci], x, 1) : x - a0;
+            e.oi++;
+            if (e.oi >= e.ngridmax) {
+                e.err = 13;
+                return false;
+            }
+        }
+    } else {  // point of another function (:1417-1516)
+        e.ci = (int)e.oix[e.oj - 1];
+        double t = env_fn(e, e.ci, x);
+        if (t < fv) {
+            int cj = -1;
+            for (int j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0 || j == f || j == e.ci) continue;
+                t = env_fn(e, j, x);
+                if ((fv < t) || (fv == t && j < cj)) fv = t, cj = j;
+            }
+            env_reset_marks(e);
+            if (cj == -1) {
+                env_crossing(e, e.ci, f, 1);
+                if (e.err) return false;
+                env_push(e, x, fv, e.c[self]);
+                if (e.oi >= e.ngridmax) {
+                    e.err = 13;
+                    return false;
+                }
+            } else {
+                env_crossing(e, e.ci, cj, 1);
+                if (e.err) return false;
+                if (x == bound) {
+                    double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
+                    env_push(e, x, vv, pp);
+                }
+            }
+        } else if (x == bound) {
+            double vv = env_fn(e, e.ci, x), pp = env_policy(e, e.ci, x);
+            env_push(e, x, vv, pp);
+        }
+    }
+    e.cur[f] = MS_MIN(e.cur[f] + 1, e.dims[f] - 2);
+    return true;
+}
+
+// Plain sequential walk (one lane, or every lane of a wave redundantly).
+static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
+{
+    env_begin(e);
+    for (int i = 0; i < npts && e.m[i] <= e.bound && !e.err; i++)
+        if (!env_step(e, i)) return;
+}
+
+// ---- wave-cooperative walk ------------------------------------------------------------------------------
+// The walk only does something irregular at regime changes (a crossing, the first and the last grid value);
+// everywhere else a sorted point is either KEPT (it belongs to the current max function and nothing is above
+// it), SKIPPED (another function, below the current max) or a DUPLICATE of the last kept grid value.  These
+// three outcomes depend on the walk's state only through (a) the current max function and (b) how many points
+// of each function precede the position -- and for grid values strictly below `bound` the latter is a pure
+// count (cur[j] = count_j - 1: no function has run out of points yet, so the clamp of :1517 is inactive).  So
+// the 64 lanes classify 64 consecutive positions at once, the leading run of regular positions is committed
+// with ballot/popcount compaction in order, and the first irregular position is handed to env_step() with
+// cur[] rebuilt from the counts.  Every lane executes env_step redundantly (uniform control flow, identical
+// stores).  Output is identical to env_walk(); the CPU harness checks that bit for bit.
+static __device__ __forceinline__ int env_count_before(const EnvCtx &e, int j, int p)
+{
+    // number of points of function j at sorted positions < p (the position list of j is ascending)
+    const int *lst = e.rank + e.fstart[j];
+    int lo = 0, hi = e.dims[j];
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (lst[mid] < p)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+static __device__ __forceinline__ double env_fn_at(EnvCtx &e, int j, int curj, double x)
+{
+    if (curj >= 0) return env_seg(e, j, curj, x, 0);
+    if (env_evf(e, j) == -INFINITY) return -INFINITY;
+    return env_analytic(e, j, x);
+}
+
+// lane 0 takes one generic step; the few scalars the other lanes need are broadcast afterwards
+static __device__ __forceinline__ bool env_step_lane0(EnvCtx &e, int i, int lane)
+{
+    int ok = 1;
+    if (lane == 0) ok = env_step(e, i) ? 1 : 0;
+    __threadfence_block();  // lane 0's stores (outputs, cursors) before the other lanes' loads
+    e.oi = __shfl(e.oi, 0);
+    e.oj = __shfl(e.oj, 0);
+    e.err = __shfl(e.err, 0);
+    return __shfl(ok, 0) != 0;
+}
+
+static __device__ __forceinline__ void env_walk_wave(EnvCtx &e, int npts)
+{
+    const int lane = threadIdx.x & (EG_WAVE - 1);
+#ifdef EGDST_SEQ_WALK  // diagnostic build: the plain sequential walk on lane 0
+    if (lane == 0) env_walk(e, npts);
+    __threadfence_block();
+    e.oi = __shfl(e.oi, 0);
+    e.oj = __shfl(e.oj, 0);
+    e.err = __shfl(e.err, 0);
+    return;
+#endif
+    {   // env_begin: every lane needs `bound`; the cursor array is shared, lane 0 initialises it
+        double bound = INFINITY;
+        for (int f = 0; f < e.nf; f++)
+            if (e.dims[f] > 0) {
+                double last = e.m[env_at(e, f, e.dims[f] - 1)];
+                if (last < bound) bound = last;
+            }
+        e.bound = bound;
+        e.oi = e.oj = 0;
+        e.ci = 0;
+        if (lane == 0)
+            for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
+        e.err = __shfl(e.err, 0);
+    }
+    int i = 0;
+    // the first point(s), until a current-max function exists
+    while (i < npts && e.m[i] <= e.bound && !e.err && e.oj == 0) {
+        if (!env_step_lane0(e, i, lane)) return;
+        i++;
+    }
+    while (i < npts && !e.err) {
+        const int p = i + lane;
+        const bool valid = p < npts && e.m[p] < e.bound;
+        const unsigned long long vmask = __ballot(valid);
+        if (!(vmask & 1ull)) break;  // position i itself is at (or beyond) the bound: sequential tail
+        const int pm = (int)e.oix[e.oj - 1];
+        const double lastg = e.oi > 0 ? e.og[e.oi - 1] : -INFINITY;
+        int cls = 1;  // 0 keep, 1 skip, 2 event
+        double x = 0, fv = 0, cc = 0;
+        if (valid) {
+            const int f = e.f[p];
+            x = e.m[p];
+            fv = e.v[p];
+            cc = e.c[p];
+            if (f < 0 || f >= e.nf || e.dims[f] <= 0)
+                cls = 2;  // let env_step report the inconsistency
+            else if (f == pm) {
+                cls = 0;
+                for (int j = 0; j < e.nf; j++) {
+                    if (e.dims[j] <= 0 || j == f) continue;
+                    const double t = env_fn_at(e, j, env_count_before(e, j, p) - 1, x);
+                    if (fv < t) {
+                        cls = 2;
+                        break;
+                    }
+                }
+            } else {
+                const double t = env_fn_at(e, pm, env_count_before(e, pm, p) - 1, x);
+                cls = (t < fv) ? 2 : 1;
+            }
+        }
+        // duplicates (:1290-1298): equal to the last kept grid value, carried in or kept earlier in this batch
+        const double xprev = __shfl_up(x, 1);
+        const bool newrun = valid && (lane == 0 || x != xprev);
+        const unsigned long long rmask = __ballot(newrun), kmask = __ballot(valid && cls == 0);
+        bool dup = false;
+        if (valid) {
+            const unsigned long long below = (1ull << lane) - 1ull;  // lanes < lane
+            const unsigned long long upto = below | (1ull << lane);
+            const int s = 63 - __clzll((long long)(rmask & upto));  // first lane of this run of equal grid values
+            const unsigned long long inrun = below & ~((1ull << s) - 1ull);
+            dup = (lastg == x) || ((kmask & inrun) != 0ull);
+        }
+        const unsigned long long emask = __ballot(valid && !dup && cls == 2);
+        const int nvalid = __popcll(vmask);
+        const int stop = emask ? (__ffsll((long long)emask) - 1) : nvalid;  // lanes [0, stop) are regular
+        const bool out = valid && lane < stop && !dup && cls == 0;
+        const unsigned long long omask = __ballot(out);
+        const int nout = __popcll(omask);
+        if (nout) {
+            if (e.oi + nout >= e.ngridmax) {  // the push that fills the grid is an error in the reference (:1378)
+                e.err = 13;
                 return;
             }
-            if (ci == f) {
-                env_push(e, x, t, e.c[self]);
-                if (e.oi >= e.ngridmax) {
-                    e.err = 13;
-                    return;
-                }
+            if (out) {
+                const int d = e.oi + __popcll(omask & ((1ull << lane) - 1ull));
+                e.og[d] = x;
+                e.ov[d] = fv;
+                e.oc[d] = cc;
             }
-        } else if ((int)e.oix[e.oj - 1] == f) {  // point of the current max function (:1348-1416)
-            int above = 0, j;
-            double t;
-            for (j = 0; j < e.nf; j++) {
-                if (e.dims[j] <= 0 || j == f) continue;
-                t = env_fn(e, j, x);
-                if (fv < t) {
-                    above = 1;
-                    if (x != bound) break;
-                    fv = t;
-                    ci = j;
-                }
-            }
-            if (!above) {
-                env_push(e, x, fv, e.c[self]);
-                if (e.oi == e.ngridmax) {
-                    e.err = 13;
-                    return;
-                }
-            } else if (x != bound) {
-                env_reset_marks(e);
-                env_crossing(e, f, j, 0);
-                if (e.err) return;
-            } else {
-                env_reset_marks(e);
-                env_crossing(e, f, ci, 1);
-                if (e.err) return;
-                e.og[e.oi] = x;
-                e.ov[e.oi] = env_fn(e, ci, x);
-                // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
-                e.oc[e.oi] = (e.cur[ci] >= 0) ? env_seg(e, ci, e.cur[ci], x, 1) : x - a0;
-                e.oi++;
-                if (e.oi >= e.ngridmax) {
-                    e.err = 13;
-                    return;
-                }
-            }
-        } else {  // point of another function (:1417-1516)
-            ci = (int)e.oix[e.oj - 1];
-            double t = env_fn(e, ci, x);
-            if (t < fv) {
-                int cj = -1;
-                for (int j = 0; j < e.nf; j++) {
-                    if (e.dims[j] <= 0 || j == f || j == ci) continue;
-                    t = env_fn(e, j, x);
-                    if ((fv < t) || (fv == t && j < cj)) fv = t, cj = j;
-                }
-                env_reset_marks(e);
-                if (cj == -1) {
-                    env_crossing(e, ci, f, 1);
-                    if (e.err) return;
-                    env_push(e, x, fv, e.c[self]);
-                    if (e.oi >= e.ngridmax) {
-                        e.err = 13;
-                        return;
-                    }
-                } else {
-                    env_crossing(e, ci, cj, 1);
-                    if (e.err) return;
-                    if (x == bound) {
-                        double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
-                        env_push(e, x, vv, pp);
-                    }
-                }
-            } else if (x == bound) {
-                double vv = env_fn(e, ci, x), pp = env_policy(e, ci, x);
-                env_push(e, x, vv, pp);
-            }
+            e.oi += nout;
+            __threadfence_block();
         }
-        e.cur[f] = MS_MIN(e.cur[f] + 1, e.dims[f] - 2);
+        i += stop;
+        if (stop < nvalid) {  // irregular position: rebuild the per-function cursors and take the generic step
+            if (lane == 0)
+                for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+            if (!env_step_lane0(e, i, lane)) return;
+            i++;
+        }
     }
+    if (e.err) return;
+    // tail: grid values at the bound (the last point of the shortest function) -- at most a few positions
+    if (lane == 0) {
+        for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+        for (; i < npts && e.m[i] <= e.bound && !e.err; i++)
+            if (!env_step(e, i)) break;
+    }
+    __threadfence_block();
+    e.oi = __shfl(e.oi, 0);
+    e.oj = __shfl(e.oj, 0);
+    e.err = __shfl(e.err, 0);
 }

@@ -21,15 +21,16 @@
 #include <string.h>
 #include <stdlib.h>
 
-#include "egdst_device.h"
-#include "egdst_envelope.h"
-#include "../../include/egdst.h"
-
-#ifndef WAVE  // the sanitizer harness (tests/cpu_emu) overrides these with 1
+#ifndef WAVE  // the sanitizer harness (tests/cpu_emu) overrides these
 #define WAVE 64
 #define GRID_BS 256
 #define ENV_BS 256
 #endif
+#define EG_WAVE WAVE
+
+#include "egdst_device.h"
+#include "egdst_envelope.h"
+#include "../../include/egdst.h"
 
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ void eg_fail(const Batch &b, int draw, int it, int ist, int code)
@@ -655,9 +656,19 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         }                                                \
         return;                                          \
     } while (0)
-__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal)
+#ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
+#define EG_DYN_LDS(name) static double name[20480]
+#else
+#define EG_DYN_LDS(name) extern __shared__ double name[]
+#endif
+#define ENV_SMALLF 64
+static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
+// lcap: sorted points that fit the dynamic LDS (5 arrays: M, C, V as doubles; function id and position list as ints)
+__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal, int lcap)
 {
+    EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_BS];
+    __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
@@ -688,7 +699,9 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     int *sF = b.sF + wo;
     int *rank = b.rank + wo;
     const size_t fo = ((size_t)draw * MS_NST + ist) * (size_t)(ngridmax + MS_ND + 2);
-    int *fstart = b.fstart + fo, *fdims = b.fdims + fo, *fcur = b.fcur + fo, *fmark = b.fmark + fo;
+    int *gfstart = b.fstart + fo, *gfdims = b.fdims + fo, *gfcur = b.fcur + fo, *gfmark = b.fmark + fo;
+    double *Lm = dynlds, *Lc = Lm + lcap, *Lv = Lc + lcap;
+    int *Lf = (int *)(Lv + lcap), *Lr = Lf + lcap;
     const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)ngridmax;
     double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eo, *eIX = b.eIX + eo;
     int *stack = b.stack + 2 * eo;
@@ -789,6 +802,9 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                 if (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]) nfold++;
             nfold = blk_sum(nfold, sh);
             if (nfold > 0) {
+                const bool smallf = (id + nfold + 1) <= ENV_SMALLF;
+                int *fstart = smallf ? s_fstart : gfstart, *fdims = smallf ? s_fdims : gfdims;
+                int *fcur = smallf ? s_fcur : gfcur, *fmark = smallf ? s_fmark : gfmark;
                 // input with one constant-extrapolation point appended to every closed piece (:822-835)
                 int carry = 0, lastfold = 0;
                 for (int base = 0; base < cnt; base += ENV_BS) {
@@ -834,19 +850,22 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                         fdims[f] = ((f + 1 < nf) ? fstart[f + 1] : total) - fstart[f];
                 }
                 __syncthreads();
-                blk_rank_sort(total, nf, sM, sC, sV, sF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw);
+                const bool inl = total <= lcap;  // sorted stream and position lists in LDS when they fit
+                double *zM = inl ? Lm : qM, *zC = inl ? Lc : qC, *zV = inl ? Lv : qV;
+                int *zF = inl ? Lf : qF, *zR = inl ? Lr : rank;
+                blk_rank_sort(total, nf, sM, sC, sV, sF, fstart, fdims, zM, zC, zV, zF, zR, sh, &s_oob, b.dbg + 16 * draw);
                 if (s_oob) ENV_FAIL(2704);
-                if (tid == 0) {
+                if (tid < WAVE) {  // wave 0 walks; every lane carries the same state
                     EnvCtx e;
                     e.E = &E;
                     e.it = it;
                     e.ist = ist;
                     e.nf = nf;
-                    e.m = qM;
-                    e.c = qC;
-                    e.v = qV;
-                    e.f = qF;
-                    e.rank = rank;
+                    e.m = zM;
+                    e.c = zC;
+                    e.v = zV;
+                    e.f = zF;
+                    e.rank = zR;
                     e.fstart = fstart;
                     e.dims = fdims;
                     e.cur = fcur;
@@ -867,7 +886,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                     e.npts = total;
                     e.dbg = b.dbg + 16 * draw;
                     e.err = 0;
-                    env_walk(e, total);
+                    env_walk_wave(e, total);
                     if (!e.err && e.oi >= ngridmax) e.err = 17;  // (:884)
                     s_err = e.err;
                     s_n = e.oi;
@@ -933,24 +952,28 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         }
     }
     if (!done) {
+        int *fstart = s_fstart, *fdims = s_fdims, *fcur = s_fcur, *fmark = s_fmark;
+        const bool inl = nall <= lcap;
+        double *zM = inl ? Lm : qM, *zC = inl ? Lc : qC, *zV = inl ? Lv : qV;
+        int *zF = inl ? Lf : qF, *zR = inl ? Lr : rank;
         for (int f = tid; f < MS_ND; f += ENV_BS) {
             fstart[f] = s_start[f];
             fdims[f] = s_cnt[f];
         }
         __syncthreads();
-        blk_rank_sort(nall, MS_ND, pM, pC, pV, pF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw);
+        blk_rank_sort(nall, MS_ND, pM, pC, pV, pF, fstart, fdims, zM, zC, zV, zF, zR, sh, &s_oob, b.dbg + 16 * draw);
         if (s_oob) ENV_FAIL(2714);
-        if (tid == 0) {
+        if (tid < WAVE) {  // wave 0 walks; every lane carries the same state
             EnvCtx e;
             e.E = &E;
             e.it = it;
             e.ist = ist;
             e.nf = MS_ND;
-            e.m = qM;
-            e.c = qC;
-            e.v = qV;
-            e.f = qF;
-            e.rank = rank;
+            e.m = zM;
+            e.c = zC;
+            e.v = zV;
+            e.f = zF;
+            e.rank = zR;
             e.fstart = fstart;
             e.dims = fdims;
             e.cur = fcur;
@@ -971,7 +994,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
             e.npts = nall;
             e.dbg = b.dbg + 16 * draw;
             e.err = 0;
-            env_walk(e, nall);
+            env_walk_wave(e, nall);
             if (!e.err && e.oi == 0) e.err = 16;
             s_err = e.err;
             s_n = e.oi;

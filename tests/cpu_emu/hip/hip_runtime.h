@@ -44,10 +44,67 @@ static inline void __syncthreads()
 {
     if (emu_block_threads > 1) pthread_barrier_wait(&emu_barrier);
 }
+#ifndef WAVE
+#define WAVE 1
+#endif
+#if WAVE == 1
 template <class T> static inline T __shfl(T v, int) { return v; }
+template <class T> static inline T __shfl_up(T v, int) { return v; }
 static inline int __any(int x) { return x != 0; }
 static inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
+#else
+// Real multi-lane waves: the WAVE consecutive threads of a workgroup exchange values through a per-wave slot
+// array and a per-wave barrier.  Every lane of the wave must reach the same sequence of collectives (that is
+// also what the GPU requires of the code paths that use them).
+#define EMU_MAX_WAVES 64
+static pthread_barrier_t emu_wave_barrier[EMU_MAX_WAVES];
+static unsigned long long emu_wave_slot[EMU_MAX_WAVES][WAVE];
+static inline void emu_exchange(unsigned long long mine, unsigned long long *all)
+{
+    const int w = threadIdx.x / WAVE, l = threadIdx.x % WAVE;
+    emu_wave_slot[w][l] = mine;
+    pthread_barrier_wait(&emu_wave_barrier[w]);
+    for (int k = 0; k < WAVE; k++) all[k] = emu_wave_slot[w][k];
+    pthread_barrier_wait(&emu_wave_barrier[w]);
+}
+template <class T> static inline unsigned long long emu_pack(T v)
+{
+    unsigned long long u = 0;
+    memcpy(&u, &v, sizeof(T));
+    return u;
+}
+template <class T> static inline T emu_unpack(unsigned long long u)
+{
+    T v;
+    memcpy(&v, &u, sizeof(T));
+    return v;
+}
+template <class T> static inline T __shfl(T v, int src)
+{
+    unsigned long long all[WAVE];
+    emu_exchange(emu_pack(v), all);
+    return emu_unpack<T>(all[src % WAVE]);
+}
+template <class T> static inline T __shfl_up(T v, int d)
+{
+    unsigned long long all[WAVE];
+    emu_exchange(emu_pack(v), all);
+    const int l = threadIdx.x % WAVE;
+    return l >= d ? emu_unpack<T>(all[l - d]) : v;
+}
+static inline unsigned long long __ballot(int x)
+{
+    unsigned long long all[WAVE], m = 0;
+    emu_exchange(x ? 1ull : 0ull, all);
+    for (int k = 0; k < WAVE; k++) m |= (all[k] & 1ull) << k;
+    return m;
+}
+static inline int __any(int x) { return __ballot(x) != 0ull; }
+#endif
+static inline void __threadfence_block() { __sync_synchronize(); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int atomicCAS(int *p, int cmp, int val)
 {
     int old = *p;
@@ -83,6 +140,13 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memc
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 
+#if WAVE > 1
+#define EMU_WAVE_INIT(n) for (unsigned w_ = 0; w_ < ((n) + WAVE - 1) / WAVE && w_ < EMU_MAX_WAVES; w_++) pthread_barrier_init(&emu_wave_barrier[w_], nullptr, WAVE)
+#define EMU_WAVE_DONE(n) for (unsigned w_ = 0; w_ < ((n) + WAVE - 1) / WAVE && w_ < EMU_MAX_WAVES; w_++) pthread_barrier_destroy(&emu_wave_barrier[w_])
+#else
+#define EMU_WAVE_INIT(n)
+#define EMU_WAVE_DONE(n)
+#endif
 // Default: workgroups run one after another; the threads of a workgroup run concurrently (std::thread) and
 // meet at a pthread barrier, so ThreadSanitizer sees intra-workgroup races.  With EMU_PARALLEL_BLOCKS (and
 // one-thread workgroups) all workgroups of a launch run concurrently instead: inter-workgroup races.
@@ -111,6 +175,7 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
         blockDim = b_;                                                              \
         emu_block_threads = (int)b_.x;                                              \
         if (b_.x > 1) pthread_barrier_init(&emu_barrier, nullptr, b_.x);            \
+        EMU_WAVE_INIT(b_.x);                                                        \
         for (unsigned bz_ = 0; bz_ < g_.z; bz_++)                                   \
             for (unsigned by_ = 0; by_ < g_.y; by_++)                               \
                 for (unsigned bx_ = 0; bx_ < g_.x; bx_++) {                         \
@@ -130,5 +195,6 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
                     }                                                               \
                 }                                                                   \
         if (b_.x > 1) pthread_barrier_destroy(&emu_barrier);                        \
+        EMU_WAVE_DONE(b_.x);                                                        \
     } while (0)
 #endif

@@ -10,12 +10,12 @@ from oracle_harness import Oracle
 from parity import compare
 
 
-def run(model, P, keep_history, sanitize='address', env_bs=1):
+def run(model, P, keep_history, sanitize='address', env_bs=1, wave=1):
     text = codegen.generate_modelspec(model)
     d = os.path.join(build.MODELS_DIR, build.model_tag(model, text))
     os.makedirs(d, exist_ok=True)
     open(os.path.join(d, 'modelspec.h'), 'w').write(text)
-    lib = runtime.ModelLibrary(build_emu.build(d, sanitize, env_bs))
+    lib = runtime.ModelLibrary(build_emu.build(d, sanitize, env_bs, False, wave))
     s = runtime.Solver(lib, model.descriptor(), ndraw=len(P), keep_history=keep_history)
     s.set_params(P)
     s.solve(raise_on_error=False)
