@@ -12,33 +12,58 @@
 #define EG_WAVE 64
 #endif
 
-struct EnvCtx {
+// Address spaces are kept in the TYPES: the sorted stream is either LDS- or global-resident (template
+// parameter L), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
+// avoided on purpose -- selecting between LDS- and global-derived generic pointers made hipcc's backend fail
+// ("Illegal instruction detected ... src_shared_base") on one model, and typed LDS accesses are ds_* ops anyway.
+#ifdef EGDST_EMU
+#define EG_LDS_AS
+#else
+#define EG_LDS_AS __attribute__((address_space(3)))
+#endif
+typedef EG_LDS_AS double eg_ldsd;
+typedef EG_LDS_AS int eg_ldsi;
+template <bool L> struct EgMem {
+    typedef double D;
+    typedef int I;
+};
+template <> struct EgMem<true> {
+    typedef eg_ldsd D;
+    typedef eg_ldsi I;
+};
+
+template <bool L> struct EnvCtxT {
     const ms_env *E;
     int it, ist, nf;
-    const double *m, *c, *v;  // sorted points
-    const int *f;
-    const int *rank, *fstart;
-    int *dims, *cur, *mark, *stack;
+    const typename EgMem<L>::D *m, *c, *v;  // sorted points
+    const typename EgMem<L>::I *f;
+    const typename EgMem<L>::I *rank;       // position lists
+    const eg_ldsi *fstart;
+    eg_ldsi *dims, *cur, *mark;
+    eg_ldsi *cnt;   // wave walk: points of each function at sorted positions before the current one
+    eg_ldsi *stack;
     int stackcap;
     // expected value at a0 per function: primary -> evfa0[f]; secondary -> (f==sec_id ? sec_ev : -inf)
-    const double *evfa0;
+    const eg_ldsd *evfa0;
     int sec_id;
     double sec_ev;
     double *og, *ov, *oc, *oth, *oix;
     int oi, oj, ngridmax, nthrhmax;
     int cap, npts;  // capacity of rank[] and number of sorted points (bounds guard)
     double bound;   // min over functions of the last grid point
+    double lastg;   // grid value of the last output row (og[oi-1]); kept in a register so the walk never reads og back
+    int pm;         // function that is currently the max ((int)oix[oj-1])
     int ci;         // the reference's `ci` (persists across iterations)
     int *dbg;       // [16] diagnostics of a tripped guard
     int err;
 };
 
-static __device__ __forceinline__ double env_evf(const EnvCtx &e, int f)
+template <bool L> static __device__ __forceinline__ double env_evf(const EnvCtxT<L> &e, int f)
 {
     if (e.sec_id >= 0) return f == e.sec_id ? e.sec_ev : -INFINITY;
     return e.evfa0[f];
 }
-static __device__ __forceinline__ int env_at(EnvCtx &e, int f, int k)
+template <bool L> static __device__ __forceinline__ int env_at(EnvCtxT<L> &e, int f, int k)
 {
     const int o = e.fstart[f] + k;
     if (o < 0 || o >= e.cap) {  // never expected; turns a wild access into an error code
@@ -63,7 +88,7 @@ static __device__ __forceinline__ int env_at(EnvCtx &e, int f, int k)
 
 // value (which=0) or consumption (which=1) of f on the segment that starts at its k-th point; -inf outside
 // the segment: "No extrapolation allowed: this is essential for the correct envelop" (linter2, :1585-1593)
-static __device__ __forceinline__ double env_seg(EnvCtx &e, int f, int k, double x, int which)
+template <bool L> static __device__ __forceinline__ double env_seg(EnvCtxT<L> &e, int f, int k, double x, int which)
 {
     int a = env_at(e, f, k), b = env_at(e, f, k + 1);
     double ga = e.m[a], gb = e.m[b];
@@ -74,7 +99,7 @@ static __device__ __forceinline__ double env_seg(EnvCtx &e, int f, int k, double
     return fb * (x - ga) / (gb - ga) + fa * (gb - x) / (gb - ga);
 }
 
-static __device__ __forceinline__ double env_analytic(const EnvCtx &e, int f, double x)
+template <bool L> static __device__ __forceinline__ double env_analytic(const EnvCtxT<L> &e, int f, double x)
 {
     ms_pv cv;
     cv.it = e.it;
@@ -84,14 +109,14 @@ static __device__ __forceinline__ double env_analytic(const EnvCtx &e, int f, do
     return ms_utility(e.E, &cv, x - e.E->a0) + ms_discount(e.E, &cv) * env_evf(e, f);
 }
 
-static __device__ __forceinline__ double env_fn(EnvCtx &e, int f, double x)  // funcvalue, :1553-1567
+template <bool L> static __device__ __forceinline__ double env_fn(EnvCtxT<L> &e, int f, double x)  // funcvalue, :1553-1567
 {
     if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 0);
     if (env_evf(e, f) == -INFINITY) return -INFINITY;
     return env_analytic(e, f, x);
 }
 
-static __device__ __forceinline__ double env_policy(EnvCtx &e, int f, double x)  // :1406-1408, :1859-1864
+template <bool L> static __device__ __forceinline__ double env_policy(EnvCtxT<L> &e, int f, double x)  // :1406-1408, :1859-1864
 {
     if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 1);
     if (env_evf(e, f) == -INFINITY) return EG_ZEROC;
@@ -101,7 +126,7 @@ static __device__ __forceinline__ double env_policy(EnvCtx &e, int f, double x) 
 static __device__ __forceinline__ double env_sgn(double x) { return x > 0 ? 1.0 : -1.0; }
 
 // brsolve (:1918-1968): bisection between an analytic value function `fa` and the segment (fl,kl)
-static __device__ __forceinline__ void env_bisect(EnvCtx &e, double *b0, double *b1, int fl, int kl, int fa)
+template <bool L> static __device__ __forceinline__ void env_bisect(EnvCtxT<L> &e, double *b0, double *b1, int fl, int kl, int fa)
 {
     for (;;) {
         double f0 = env_analytic(e, fa, *b0), f1 = env_analytic(e, fa, *b1);
@@ -130,7 +155,7 @@ static __device__ __forceinline__ void env_bisect(EnvCtx &e, double *b0, double 
 }
 
 // thresholds (:1596-1915)
-static __device__ __forceinline__ void env_crossing(EnvCtx &e, int pri0, int nwi0, int mode)
+template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
 {
     const double a0 = e.E->a0;
     int sp = 0;
@@ -218,11 +243,13 @@ static __device__ __forceinline__ void env_crossing(EnvCtx &e, int pri0, int nwi
             continue;
         }
         const double pol0 = env_policy(e, pri, x), pol1 = env_policy(e, nwi, x);
+        double gx = x;  // grid value of the row written last (kept for the duplicate test)
         e.og[e.oi] = x;
         e.ov[e.oi] = top;
         e.oc[e.oi] = (pol0 + pol1) / 2;
         e.oth[e.oj] = x;
         e.oix[e.oj] = nwi;
+        e.pm = nwi;
         e.oi += 1;
         e.oj += 1;
         if (e.oi >= e.ngridmax) {
@@ -235,10 +262,12 @@ static __device__ __forceinline__ void env_crossing(EnvCtx &e, int pri0, int nwi
         }
         if (env_evf(e, nwi) == -INFINITY && e.cur[nwi] == -1) {  // :1892-1900
             e.oc[e.oi - 1] = pol0;
-            e.og[e.oi - 1] = e.og[e.oi - 1] - EG_TOL;
+            gx = x - EG_TOL;
+            e.og[e.oi - 1] = gx;
         } else if (EG_DPD > 0) {  // double point at the kink, :1902-1913
             e.oc[e.oi - 1] = pol0;
-            e.og[e.oi] = x + EG_DPD;
+            gx = x + EG_DPD;
+            e.og[e.oi] = gx;
             e.ov[e.oi] = top;
             e.oc[e.oi] = pol1;
             e.oi += 1;
@@ -247,25 +276,27 @@ static __device__ __forceinline__ void env_crossing(EnvCtx &e, int pri0, int nwi
                 return;
             }
         }
+        e.lastg = gx;
     }
 }
 
-static __device__ __forceinline__ void env_reset_marks(EnvCtx &e)
+template <bool L> static __device__ __forceinline__ void env_reset_marks(EnvCtxT<L> &e)
 {
     for (int l = 0; l < e.nf; l++) e.mark[l] = (e.dims[l] > 0 ? 0 : 1);
 }
-static __device__ __forceinline__ void env_push(EnvCtx &e, double g, double v, double c)
+template <bool L> static __device__ __forceinline__ void env_push(EnvCtxT<L> &e, double g, double v, double c)
 {
     e.og[e.oi] = g;
     e.ov[e.oi] = v;
     e.oc[e.oi] = c;
     e.oi++;
+    e.lastg = g;
 }
 
 // ---- the merge walk (:1262-1550) ------------------------------------------------------------------------
 // env_begin: state before the first point; env_step: one iteration of the reference's while loop for the
 // sorted position i (returns false when the walk must stop).  dims[] must hold the points per function.
-static __device__ __forceinline__ void env_begin(EnvCtx &e)
+template <bool L> static __device__ __forceinline__ void env_begin(EnvCtxT<L> &e)
 {
     for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
     double bound = INFINITY;  // min over functions of the last grid point (:1266-1271)
@@ -277,9 +308,11 @@ static __device__ __forceinline__ void env_begin(EnvCtx &e)
     e.bound = bound;
     e.oi = e.oj = 0;
     e.ci = 0;
+    e.lastg = -INFINITY;
+    e.pm = -1;
 }
 
-static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
+template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e, int i)
 {
     const double a0 = e.E->a0, bound = e.bound;
     const int f = e.f[i];
@@ -290,7 +323,7 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
         e.err = 2708;
         return false;
     }
-    if (e.oi > 0 && e.og[e.oi - 1] == x) {  // duplicate grid point (:1290-1298)
+    if (e.oi > 0 && e.lastg == x) {  // duplicate grid point (:1290-1298)
         e.cur[f]++;
         return true;
     }
@@ -307,6 +340,7 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
         }
         e.oth[e.oj] = a0;
         e.oix[e.oj] = e.ci;
+        e.pm = e.ci;
         e.oj++;
         if (e.oj >= e.nthrhmax) {
             e.err = 20;
@@ -319,7 +353,7 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
                 return false;
             }
         }
-    } else if ((int)e.oix[e.oj - 1] == f) {  // point of the current max function (:1348-1416)
+    } else if (e.pm == f) {  // point of the current max function (:1348-1416)
         int above = 0, j;
         double t;
         for (j = 0; j < e.nf; j++) {
@@ -346,6 +380,7 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
             env_reset_marks(e);
             env_crossing(e, f, e.ci, 1);
             if (e.err) return false;
+            e.lastg = x;
             e.og[e.oi] = x;
             e.ov[e.oi] = env_fn(e, e.ci, x);
             // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
@@ -357,7 +392,7 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
             }
         }
     } else {  // point of another function (:1417-1516)
-        e.ci = (int)e.oix[e.oj - 1];
+        e.ci = e.pm;
         double t = env_fn(e, e.ci, x);
         if (t < fv) {
             int cj = -1;
@@ -392,13 +427,15 @@ static __device__ __forceinline__ bool env_step(EnvCtx &e, int i)
     return true;
 }
 
-// Plain sequential walk (one lane, or every lane of a wave redundantly).
-static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
+#ifdef EGDST_SEQ_WALK
+// Plain sequential walk (diagnostic build only).
+template <bool L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e, int npts)
 {
     env_begin(e);
     for (int i = 0; i < npts && e.m[i] <= e.bound && !e.err; i++)
         if (!env_step(e, i)) return;
 }
+#endif
 
 // ---- wave-cooperative walk ------------------------------------------------------------------------------
 // The walk only does something irregular at regime changes (a crossing, the first and the last grid value);
@@ -411,10 +448,10 @@ static __device__ __forceinline__ void env_walk(EnvCtx &e, int npts)
 // with ballot/popcount compaction in order, and the first irregular position is handed to env_step() with
 // cur[] rebuilt from the counts.  Every lane executes env_step redundantly (uniform control flow, identical
 // stores).  Output is identical to env_walk(); the CPU harness checks that bit for bit.
-static __device__ __forceinline__ int env_count_before(const EnvCtx &e, int j, int p)
+template <bool L> static __device__ __forceinline__ int env_count_before(const EnvCtxT<L> &e, int j, int p)
 {
     // number of points of function j at sorted positions < p (the position list of j is ascending)
-    const int *lst = e.rank + e.fstart[j];
+    const typename EgMem<L>::I *lst = e.rank + e.fstart[j];
     int lo = 0, hi = e.dims[j];
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -426,26 +463,47 @@ static __device__ __forceinline__ int env_count_before(const EnvCtx &e, int j, i
     return lo;
 }
 
-static __device__ __forceinline__ double env_fn_at(EnvCtx &e, int j, int curj, double x)
+template <bool L> static __device__ __forceinline__ double env_fn_at(EnvCtxT<L> &e, int j, int curj, double x)
 {
     if (curj >= 0) return env_seg(e, j, curj, x, 0);
     if (env_evf(e, j) == -INFINITY) return -INFINITY;
     return env_analytic(e, j, x);
 }
 
+// value of function j at x given that cj of its points precede the position (wave walk; no bounds guards: below the
+// bound every function still has a point ahead, so cj <= dims[j]-1)
+template <bool L> static __device__ __forceinline__ double env_fn_cnt(EnvCtxT<L> &e, int j, int cj, double x)
+{
+    if (cj >= 1) {
+        const int base = e.fstart[j] + cj - 1;
+        const int a = e.rank[base], b = e.rank[base + 1];
+        const double ga = e.m[a], gb = e.m[b], fa = e.v[a], fb = e.v[b];
+        if (x == ga) return fa;
+        if (x < ga) return -INFINITY;
+        if (x > gb) return -INFINITY;
+        return fb * (x - ga) / (gb - ga) + fa * (gb - x) / (gb - ga);
+    }
+    if (env_evf(e, j) == -INFINITY) return -INFINITY;
+    return env_analytic(e, j, x);
+}
+
 // lane 0 takes one generic step; the few scalars the other lanes need are broadcast afterwards
-static __device__ __forceinline__ bool env_step_lane0(EnvCtx &e, int i, int lane)
+template <bool L> static __device__ __forceinline__ bool env_step_lane0(EnvCtxT<L> &e, int i, int lane, double *lastg, int *pm)
 {
     int ok = 1;
-    if (lane == 0) ok = env_step(e, i) ? 1 : 0;
-    __threadfence_block();  // lane 0's stores (outputs, cursors) before the other lanes' loads
+    if (lane == 0) {
+        e.lastg = *lastg;  // rows committed by the batches since the last generic step
+        ok = env_step(e, i) ? 1 : 0;
+    }
     e.oi = __shfl(e.oi, 0);
     e.oj = __shfl(e.oj, 0);
     e.err = __shfl(e.err, 0);
+    *lastg = __shfl(e.lastg, 0);
+    *pm = __shfl(e.pm, 0);
     return __shfl(ok, 0) != 0;
 }
 
-static __device__ __forceinline__ void env_walk_wave(EnvCtx &e, int npts)
+template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
 #ifdef EGDST_SEQ_WALK  // diagnostic build: the plain sequential walk on lane 0
@@ -455,7 +513,7 @@ static __device__ __forceinline__ void env_walk_wave(EnvCtx &e, int npts)
     e.oj = __shfl(e.oj, 0);
     e.err = __shfl(e.err, 0);
     return;
-#endif
+#else
     {   // env_begin: every lane needs `bound`; the cursor array is shared, lane 0 initialises it
         double bound = INFINITY;
         for (int f = 0; f < e.nf; f++)
@@ -466,96 +524,128 @@ static __device__ __forceinline__ void env_walk_wave(EnvCtx &e, int npts)
         e.bound = bound;
         e.oi = e.oj = 0;
         e.ci = 0;
+        e.lastg = -INFINITY;
+        e.pm = -1;
         if (lane == 0)
-            for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
+            for (int f = 0; f < e.nf; f++) e.cur[f] = -1, e.cnt[f] = 0;
         e.err = __shfl(e.err, 0);
     }
-    int i = 0;
-    // the first point(s), until a current-max function exists
-    while (i < npts && e.m[i] <= e.bound && !e.err && e.oj == 0) {
-        if (!env_step_lane0(e, i, lane)) return;
-        i++;
-    }
+    // phase 0: the first point(s) until a current-max function exists; phase 1: batches of EG_WAVE positions;
+    // phase 2: the grid values at the bound (last point of the shortest function).  One generic-step site.
+    int i = 0, pm = -1, phase = 0;
+    double lastg = -INFINITY;
+#ifdef EGDST_STAMPS
+    unsigned long long w_t0 = wall_clock64(), w_step = 0, w_batch = 0, w_nstep = 0, w_nbatch = 0;
+#define WSTAMP(acc, cnt) do { unsigned long long n_ = wall_clock64(); acc += n_ - w_t0; w_t0 = n_; cnt++; } while (0)
+#else
+#define WSTAMP(acc, cnt)
+#endif
     while (i < npts && !e.err) {
-        const int p = i + lane;
-        const bool valid = p < npts && e.m[p] < e.bound;
-        const unsigned long long vmask = __ballot(valid);
-        if (!(vmask & 1ull)) break;  // position i itself is at (or beyond) the bound: sequential tail
-        const int pm = (int)e.oix[e.oj - 1];
-        const double lastg = e.oi > 0 ? e.og[e.oi - 1] : -INFINITY;
-        int cls = 1;  // 0 keep, 1 skip, 2 event
-        double x = 0, fv = 0, cc = 0;
-        if (valid) {
-            const int f = e.f[p];
-            x = e.m[p];
-            fv = e.v[p];
-            cc = e.c[p];
-            if (f < 0 || f >= e.nf || e.dims[f] <= 0)
-                cls = 2;  // let env_step report the inconsistency
-            else if (f == pm) {
-                cls = 0;
-                for (int j = 0; j < e.nf; j++) {
-                    if (e.dims[j] <= 0 || j == f) continue;
-                    const double t = env_fn_at(e, j, env_count_before(e, j, p) - 1, x);
-                    if (fv < t) {
-                        cls = 2;
-                        break;
+        bool step_now = true;
+        if (phase != 1) {
+            if (!(e.m[i] <= e.bound)) break;
+        } else {
+            const int p = i + lane;
+            const bool valid = p < npts && e.m[p] < e.bound;
+            const unsigned long long vmask = __ballot(valid);
+            if (!(vmask & 1ull)) {  // position i is at (or beyond) the bound: sequential tail with rebuilt cursors
+                if (lane == 0)
+                    for (int j = 0; j < e.nf; j++) e.cur[j] = e.cnt[j] - 1;
+                phase = 2;
+                continue;
+            }
+            int cls = 1, f = -1;  // 0 keep, 1 skip, 2 event
+            double x = 0, fv = 0, cc = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;  // lanes < lane
+            if (valid) {
+                f = e.f[p];
+                x = e.m[p];
+                fv = e.v[p];
+                cc = e.c[p];
+                if (f < 0 || f >= e.nf || e.dims[f] <= 0)
+                    cls = 2;  // let env_step report the inconsistency
+                else
+                    cls = (f == pm) ? 0 : 1;
+            }
+            // One uniform pass over the functions: a ballot gives every lane the number of j-points that precede
+            // its position (no search), and the lanes that need f_j(x) evaluate it on j's current segment.
+            for (int j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0) continue;
+                const unsigned long long mj = __ballot(valid && f == j);
+                if (valid && cls != 2 && j != f && (f == pm || j == pm)) {
+                    const int cj = e.cnt[j] + __popcll(mj & below);
+                    if (cj >= e.dims[j])
+                        cls = 2;  // cannot happen below the bound; the generic step sorts it out
+                    else {
+                        const double t = env_fn_cnt(e, j, cj, x);
+                        if (f == pm ? (fv < t) : (t < fv)) cls = 2;
                     }
                 }
-            } else {
-                const double t = env_fn_at(e, pm, env_count_before(e, pm, p) - 1, x);
-                cls = (t < fv) ? 2 : 1;
             }
-        }
-        // duplicates (:1290-1298): equal to the last kept grid value, carried in or kept earlier in this batch
-        const double xprev = __shfl_up(x, 1);
-        const bool newrun = valid && (lane == 0 || x != xprev);
-        const unsigned long long rmask = __ballot(newrun), kmask = __ballot(valid && cls == 0);
-        bool dup = false;
-        if (valid) {
-            const unsigned long long below = (1ull << lane) - 1ull;  // lanes < lane
-            const unsigned long long upto = below | (1ull << lane);
-            const int s = 63 - __clzll((long long)(rmask & upto));  // first lane of this run of equal grid values
-            const unsigned long long inrun = below & ~((1ull << s) - 1ull);
-            dup = (lastg == x) || ((kmask & inrun) != 0ull);
-        }
-        const unsigned long long emask = __ballot(valid && !dup && cls == 2);
-        const int nvalid = __popcll(vmask);
-        const int stop = emask ? (__ffsll((long long)emask) - 1) : nvalid;  // lanes [0, stop) are regular
-        const bool out = valid && lane < stop && !dup && cls == 0;
-        const unsigned long long omask = __ballot(out);
-        const int nout = __popcll(omask);
-        if (nout) {
-            if (e.oi + nout >= e.ngridmax) {  // the push that fills the grid is an error in the reference (:1378)
-                e.err = 13;
-                return;
+            // duplicates (:1290-1298): equal to the last kept grid value, carried in or kept earlier in this batch
+            const double xprev = __shfl_up(x, 1);
+            const bool newrun = valid && (lane == 0 || x != xprev);
+            const unsigned long long rmask = __ballot(newrun), kmask = __ballot(valid && cls == 0);
+            bool dup = false;
+            if (valid) {
+                const unsigned long long upto = below | (1ull << lane);
+                const int s = 63 - __clzll((long long)(rmask & upto));  // first lane of this run of equal grid values
+                const unsigned long long inrun = below & ~((1ull << s) - 1ull);
+                dup = (lastg == x) || ((kmask & inrun) != 0ull);
             }
-            if (out) {
-                const int d = e.oi + __popcll(omask & ((1ull << lane) - 1ull));
-                e.og[d] = x;
-                e.ov[d] = fv;
-                e.oc[d] = cc;
+            const unsigned long long emask = __ballot(valid && !dup && cls == 2);
+            const int nvalid = __popcll(vmask);
+            const int stop = emask ? (__ffsll((long long)emask) - 1) : nvalid;  // lanes [0, stop) are regular
+            const bool out = valid && lane < stop && !dup && cls == 0;
+            const unsigned long long omask = __ballot(out);
+            const int nout = __popcll(omask);
+            if (nout) {
+                if (e.oi + nout >= e.ngridmax) {  // the push that fills the grid is an error in the reference (:1378)
+                    e.err = 13;
+                    return;
+                }
+                if (out) {
+                    const int d = e.oi + __popcll(omask & ((1ull << lane) - 1ull));
+                    e.og[d] = x;
+                    e.ov[d] = fv;
+                    e.oc[d] = cc;
+                }
+                e.oi += nout;
+                lastg = __shfl(x, 63 - __clzll((long long)omask));  // grid value of the last point kept in this batch
             }
-            e.oi += nout;
-            __threadfence_block();
+            {   // the positions [i, i+stop) are done: advance the per-function counts
+                const unsigned long long done = (stop >= 64) ? ~0ull : ((1ull << stop) - 1ull);
+                for (int j = 0; j < e.nf; j++) {
+                    if (e.dims[j] <= 0) continue;
+                    const unsigned long long mj = __ballot(valid && f == j);
+                    if (lane == 0) e.cnt[j] += __popcll(mj & done);
+                }
+            }
+            i += stop;
+            step_now = stop < nvalid;
+            if (step_now) {  // irregular position: cursors for the generic step straight from the counts
+                if (lane == 0)
+                    for (int j = 0; j < e.nf; j++) e.cur[j] = e.cnt[j] - 1;
+            }
+            WSTAMP(w_batch, w_nbatch);
         }
-        i += stop;
-        if (stop < nvalid) {  // irregular position: rebuild the per-function cursors and take the generic step
-            if (lane == 0)
-                for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
-            if (!env_step_lane0(e, i, lane)) return;
+        if (step_now) {
+            if (lane == 0) {
+                const int fi = e.f[i];
+                if (fi >= 0 && fi < e.nf) e.cnt[fi] += 1;  // (position i is consumed by the step below)
+            }
+            if (!env_step_lane0(e, i, lane, &lastg, &pm)) return;
             i++;
+            if (phase == 0 && e.oj > 0) phase = 1;
+            WSTAMP(w_step, w_nstep);
         }
     }
-    if (e.err) return;
-    // tail: grid values at the bound (the last point of the shortest function) -- at most a few positions
-    if (lane == 0) {
-        for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
-        for (; i < npts && e.m[i] <= e.bound && !e.err; i++)
-            if (!env_step(e, i)) break;
+#ifdef EGDST_STAMPS
+    if (lane == 0 && e.dbg) {
+        atomicAdd((unsigned long long *)e.dbg + 3, (w_nbatch << 32) | w_nstep);
+        atomicAdd((unsigned long long *)e.dbg + 4, w_step);
+        atomicAdd((unsigned long long *)e.dbg + 7, w_batch);
     }
-    __threadfence_block();
-    e.oi = __shfl(e.oi, 0);
-    e.oj = __shfl(e.oj, 0);
-    e.err = __shfl(e.err, 0);
+#endif
+#endif
 }

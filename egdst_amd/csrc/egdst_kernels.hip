@@ -96,6 +96,133 @@ __global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Closed-form log grid of end-of-period assets (egdst_solver.c:1110-1136) and the per-lane EGM evaluation of one
+// point (the serial (next state, shock) loop of egmbellman, :494-574, and the Euler inversion, :628-650).
+struct GridLims {
+    double lim1, lim2, lim3, lim3p, k3;
+    int ntogenerate;
+};
+
+static __device__ __forceinline__ double eg_grid_target(const ms_env *E, const ms_pv *cur, const GridLims &P, int n)
+{
+    // X_n of :1110-1119 (n is the value of `ngenerated` at the call)
+    if (n < (int)P.k3 - 1)
+        return -ms_trinv(E, cur, P.lim3 + (P.k3 - 1 - n) * (P.lim1 - P.lim3) / (P.k3 - 1)) + P.lim3p;
+    return ms_trinv(E, cur, P.lim3 + (n - P.k3 + 1) * (P.lim2 - P.lim3) / (P.ntogenerate - P.k3)) + P.lim3p;
+}
+
+// A_n for n > nb, where A_nb = Ab is known exactly.  The reference advances by steps A_n = A_{n-1} + (X_n - A_{n-1})
+// with a floor on negative steps (:1120-1136).  Whenever X_n and A_{n-1} are within a factor two of each other the
+// step is exact and A_n == X_n, so the chain only needs to be followed back to the last such point.
+static __device__ __forceinline__ double eg_grid_A(const ms_env *E, const ms_pv *cur, const GridLims &P, int nb, double Ab, int n)
+{
+    int k = n;
+    while (k > nb + 1) {  // find a start whose predecessor makes the step exact
+        const double xk = eg_grid_target(E, cur, P, k - 1), xk1 = eg_grid_target(E, cur, P, k);
+        const bool same = (xk > 0 && xk1 > 0) || (xk < 0 && xk1 < 0);
+        if ((same && fabs(xk1) <= 2 * fabs(xk) && fabs(xk) <= 2 * fabs(xk1)) || n - k >= 8) break;  // A_k == X_k
+        k--;
+    }
+    double prev = (k == nb + 1) ? Ab : eg_grid_target(E, cur, P, k - 1);
+    for (int j = k; j <= n; j++) {
+        double step = eg_grid_target(E, cur, P, j) - prev;
+        if (step < 0) step = MS_MAX(step, 1e-5);
+        prev += step;
+    }
+    return prev;
+}
+
+struct LaneEval {
+    int status, cnt, bist;  // 0 normal, 1 c1<=0, 2 evf=-inf, <0 hard error; evaluations; next state at the break
+    double M, C, V, R;      // point (M NaN unless normal) and the M reported back to the generator (:595-599,632)
+    double bshock, bcash;
+};
+
+static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms_env *E, const ms_pv *cur, int slot1, int draw,
+                                                        double A)
+{
+    LaneEval r;
+    const int ny = b.g.ny;
+    double rhs = 0, evf = 0, checksum = 0, c1 = 1.0;
+    int status = 0, terr = 0, cnt = 0;
+    r.bist = 0;
+    r.bshock = r.bcash = 0;
+    ms_pv nxt;
+    nxt.it = cur->it + 1;
+    nxt.id = 0;
+    nxt.cash = 0;
+    nxt.shock = 0;
+    nxt.savings = A;
+    for (nxt.ist = 0; nxt.ist < MS_NST; nxt.ist++) {
+        if (ms_feasible(E, &nxt) != 1) continue;
+        double pr1pre = 0;
+        if (MS_OPTIM_TRPRNOSH) {
+            pr1pre = ms_trpr(E, cur, &nxt, &terr);
+            if (pr1pre == 0.0) continue;
+        }
+        const int niy = (ms_sigma(E, cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
+        const Tab t = eg_tab(b, slot1, draw, nxt.ist);
+        if (t.len < 2) {
+            status = -10;
+            break;
+        }
+        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) {
+            status = -2707;
+            break;
+        }
+        for (int iy = 0; iy < niy; iy++) {
+            double pr1;
+            if (niy == 1) {
+                nxt.shock = eg_shock_mean(E, cur, &nxt);
+                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nxt, &terr);
+            } else {
+                nxt.shock = eg_shock_node(E, cur, &nxt, b.qz[iy]);
+                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nxt, &terr);
+                pr1 *= b.qw[iy];
+            }
+            if (pr1 == 0.0) continue;
+            checksum += pr1;
+            cnt++;
+            double t_rhs, t_evf;
+            c1 = eg_term(E, t, cur, &nxt, pr1, 1, &t_rhs, &t_evf);
+            if (c1 <= 0) break;
+            rhs += t_rhs;
+            evf += t_evf;
+            if (evf == -INFINITY) break;
+        }
+        if (c1 <= 0 || evf == -INFINITY) {
+            r.bist = nxt.ist;
+            r.bshock = nxt.shock;
+            r.bcash = nxt.cash;
+            break;
+        }
+    }
+    if (terr) status = -25;
+    if (status == 0) {
+        if (c1 <= 0)
+            status = 1;
+        else if (evf == -INFINITY)
+            status = 2;
+        else if (fabs(checksum - 1) > EG_TOL)
+            status = -11;
+    }
+    r.status = status;
+    r.cnt = cnt;
+    if (status == 0) {
+        rhs *= ms_discount(E, cur);
+        r.M = A + ms_utility_marginal_inverse(E, cur, rhs);
+        r.C = r.M - A;
+        r.V = ms_utility(E, cur, r.C) + ms_discount(E, cur) * evf;
+        r.R = r.M;
+    } else {
+        r.M = NAN;
+        r.C = r.V = 0;
+        r.R = (status == 1) ? b.g.a0 - 1 : r.bcash;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Full expectation at one savings guess, evaluated by one wave: lane l handles shock node l of the
 // current next-state; the weighted terms are then accumulated in (ist1 asc, iy asc) order by every
 // lane redundantly, so that sums and early exits equal the serial loop (egdst_solver.c:494-574).
@@ -266,17 +393,88 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 // the next call either starts the closed-form grid (handled by k_grid) or ends the stream
                 grid = (M < mmax && ngenerated < ntogenerate) ? 1 : 0;
                 break;
-            } else if (M < mmax && ngenerated < ntogenerate) {  // next point of the log grid (:1100-1149)
-                ncalls += 1;
+            } else if (M < mmax && ngenerated < ntogenerate) {
+                // Grid stage of the sequential stream (:1100-1149), WAVE guesses at a time: lane l evaluates the
+                // guess the generator would emit l calls from now (serial shock loop inside the lane, as k_grid
+                // does); the results are then consumed in stream order up to the first one that stops the stream
+                // or signals c1<=0 -- exactly the calls the reference would have made.
+                GridLims GL;
+                GL.lim1 = lim1, GL.lim2 = lim2, GL.lim3 = lim3, GL.lim3p = lim3p, GL.k3 = k3, GL.ntogenerate = ntogenerate;
+                const int n = ngenerated + lane;  // value of `ngenerated` at this lane's call
+                const bool can = n < ntogenerate && (ncalls + 1 + lane) < b.g.ngridmax;
+                LaneEval r;
+                r.status = 0, r.cnt = 0, r.bist = 0, r.M = NAN, r.C = r.V = r.R = 0, r.bshock = r.bcash = 0;
+                double An = last;
+                if (can) {
+                    An = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, n);
+                    r = eg_lane_eval(b, &E, &cur, slot1, draw, An);
+                }
+                const unsigned long long canm = __ballot(can);
+                const unsigned long long hardm = __ballot(can && r.status < 0);
+                const unsigned long long negm = __ballot(can && r.status == 1);
+                const unsigned long long stopm = __ballot(can && r.status != 1 && !(r.R < mmax));
+                const int ncan = __popcll(canm);  // lanes [0, ncan) hold requested-if-reached guesses
+                const int fneg = negm ? __ffsll((long long)negm) - 1 : ncan;
+                const int fstop = stopm ? __ffsll((long long)stopm) - 1 : ncan;
+                // lanes [0, take) are consumed as ordinary calls; a stopping point is itself consumed
+                const int take = (fneg <= fstop) ? fneg : min(fstop + 1, ncan);
+                const unsigned long long takem = (take >= 64) ? ~0ull : ((1ull << take) - 1ull);
+                if (hardm & (takem | (fneg < ncan && fneg <= fstop ? (1ull << fneg) : 0ull))) {
+                    const int hl = __ffsll((long long)hardm) - 1;
+                    const int code = -__shfl(r.status, hl);
+                    if (lane == 0) eg_fail(b, draw, it, ist, code);
+                    return;
+                }
+                const bool kept = lane < take && r.status == 0 && isfinite(r.M);
+                const unsigned long long keptm = __ballot(kept);
+                const unsigned long long infm = __ballot(lane < take && r.status == 2);
+                if (np + __popcll(keptm) >= b.g.ngridmax - 1) {  // (:662)
+                    if (lane == 0) eg_fail(b, draw, it, ist, 13);
+                    return;
+                }
+                if (kept) {
+                    const size_t o = co + np + __popcll(keptm & ((1ull << lane) - 1ull));
+                    b.cM[o] = r.M;
+                    b.cC[o] = r.C;
+                    b.cV[o] = r.V;
+                }
+                np += __popcll(keptm);
+                if (infm) evfa0 = -INFINITY;
+                {   // evaluations of the consumed calls (and of the c1<=0 call, if it is next)
+                    int c = (lane < take || (fneg <= fstop && lane == fneg && fneg < ncan)) ? r.cnt : 0;
+                    for (int o = WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                    nev += c;
+                }
+                if (take > 0) {
+                    last = __shfl(An, take - 1);
+                    M = __shfl(r.R, take - 1);
+                    ngenerated += take;
+                    ncalls += take;
+                }
                 keep = 1;
-                double step;
-                if (ngenerated < (int)k3 - 1)
-                    step = -ms_trinv(&E, &cur, lim3 + (k3 - 1 - ngenerated) * (lim1 - lim3) / (k3 - 1)) + lim3p - last;
-                else
-                    step = ms_trinv(&E, &cur, lim3 + (ngenerated - k3 + 1) * (lim2 - lim3) / (ntogenerate - k3)) + lim3p - last;
-                if (step < 0) step = MS_MAX(step, 1e-5);
-                last += step;
-                ngenerated += 1;
+                if (fneg <= fstop && fneg < ncan) {  // the next call hit c1<=0 (:583-621): prepare the resend
+                    const double An_ = __shfl(An, fneg);
+                    ms_pv nb;
+                    nb.it = it + 1;
+                    nb.ist = __shfl(r.bist, fneg);
+                    nb.id = 0;
+                    nb.shock = __shfl(r.bshock, fneg);
+                    nb.cash = __shfl(r.bcash, fneg);
+                    nb.savings = An_;
+                    const Tab tb = eg_tab(b, slot1, draw, nb.ist);
+                    int ierr = 0;
+                    ngenerated += 1;
+                    ncalls += 1;
+                    evfa0 = -INFINITY;
+                    M = a0 - 1;
+                    last = eg_invert_budget(&E, cur, nb, (tb.V[0] > -INFINITY) ? a0 : tb.M[1], &ierr) + EG_ZEROC;
+                    if (ierr) {
+                        if (lane == 0) eg_fail(b, draw, it, ist, ierr);
+                        return;
+                    }
+                } else if (take == 0)
+                    break;  // nothing could be requested (runaway guard, :963-978)
+                continue;   // (a consumed stopping point ends the stream at the next turn: M >= mmax)
             } else
                 break;  // stream ends (:1150-1152)
         }
@@ -392,14 +590,6 @@ __global__ void __launch_bounds__(WAVE) k_fixup(Batch b, int it)
 
 // ---------------------------------------------------------------------------------------------
 // Closed-form grid point n (1 <= n <= ngridm-1) and its EGM evaluation; one lane per point.
-static __device__ __forceinline__ double eg_grid_target(const ms_env *E, const ms_pv *cur, const ProbeOut &P, int n)
-{
-    // X_n of egdst_solver.c:1110-1119 (n is the value of `ngenerated` at the call)
-    if (n < (int)P.k3 - 1)
-        return -ms_trinv(E, cur, P.lim3 + (P.k3 - 1 - n) * (P.lim1 - P.lim3) / (P.k3 - 1)) + P.lim3p;
-    return ms_trinv(E, cur, P.lim3 + (n - P.k3 + 1) * (P.lim2 - P.lim3) / (P.ntogenerate - P.k3)) + P.lim3p;
-}
-
 __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
 {
     const int combo = blockIdx.y;
@@ -414,142 +604,62 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
     cur.ist = ist;
     cur.id = id;
     cur.cash = cur.savings = cur.shock = 0;
-    // The reference advances A by steps: A_n = A_{n-1} + (X_n - A_{n-1}) with a floor on negative steps
-    // (:1120-1136).  Whenever X_n and A_{n-1} are within a factor two of each other the step is exact and
-    // A_n == X_n, so the chain only needs to be followed back to the last such point.
-    double A;
-    {
-        int k = n;
-        while (k > 1) {  // find a start whose predecessor makes the step exact
-            double xk = eg_grid_target(&E, &cur, P, k - 1), xk1 = eg_grid_target(&E, &cur, P, k);
-            const bool same = (xk > 0 && xk1 > 0) || (xk < 0 && xk1 < 0);
-            if ((same && fabs(xk1) <= 2 * fabs(xk) && fabs(xk) <= 2 * fabs(xk1)) || n - k >= 8) break;  // A_k == X_k
-            k--;
-        }
-        double prev = (k == 1) ? P.A0 : eg_grid_target(&E, &cur, P, k - 1);
-        for (int j = k; j <= n; j++) {
-            double step = eg_grid_target(&E, &cur, P, j) - prev;
-            if (step < 0) step = MS_MAX(step, 1e-5);
-            prev += step;
-        }
-        A = prev;
-    }
+    GridLims L;
+    L.lim1 = P.lim1, L.lim2 = P.lim2, L.lim3 = P.lim3, L.lim3p = P.lim3p, L.k3 = P.k3, L.ntogenerate = P.ntogenerate;
+    const double A = eg_grid_A(&E, &cur, L, 0, P.A0, n);
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
-    const int ny = b.g.ny;
-    double rhs = 0, evf = 0, checksum = 0, c1 = 1.0, bcash = 0;
-    int status = 0, terr = 0, cnt = 0;
-    ms_pv nxt;
-    nxt.it = it + 1;
-    nxt.id = 0;
-    nxt.cash = 0;
-    nxt.shock = 0;
-    nxt.savings = A;
-    for (nxt.ist = 0; nxt.ist < MS_NST; nxt.ist++) {
-        if (ms_feasible(&E, &nxt) != 1) continue;
-        double pr1pre = 0;
-        if (MS_OPTIM_TRPRNOSH) {
-            pr1pre = ms_trpr(&E, &cur, &nxt, &terr);
-            if (pr1pre == 0.0) continue;
-        }
-        const int niy = (ms_sigma(&E, &cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
-        const Tab t = eg_tab(b, slot1, draw, nxt.ist);
-        if (t.len < 2) {
-            status = -10;
-            break;
-        }
-        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) {
-            status = -2707;
-            break;
-        }
-        for (int iy = 0; iy < niy; iy++) {
-            double pr1;
-            if (niy == 1) {
-                nxt.shock = eg_shock_mean(&E, &cur, &nxt);
-                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
-            } else {
-                nxt.shock = eg_shock_node(&E, &cur, &nxt, b.qz[iy]);
-                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
-                pr1 *= b.qw[iy];
-            }
-            if (pr1 == 0.0) continue;
-            checksum += pr1;
-            cnt++;
-            double t_rhs, t_evf;
-            c1 = eg_term(&E, t, &cur, &nxt, pr1, 1, &t_rhs, &t_evf);
-            if (c1 <= 0) break;
-            rhs += t_rhs;
-            evf += t_evf;
-            if (evf == -INFINITY) break;
-        }
-        if (c1 <= 0 || evf == -INFINITY) {
-            bcash = nxt.cash;
-            break;
-        }
-    }
+    const LaneEval r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
     const size_t o = eg_cand(b, draw, ist, id) + n;
-    if (terr) status = -25;
-    if (status == 0) {
-        if (c1 <= 0)
-            status = 1;
-        else if (evf == -INFINITY)
-            status = 2;
-        else if (fabs(checksum - 1) > EG_TOL)
-            status = -11;
-    }
-    b.cCnt[o] = cnt;
-    b.cSt[o] = status;
-    if (status == 0) {
-        rhs *= ms_discount(&E, &cur);
-        const double M = A + ms_utility_marginal_inverse(&E, &cur, rhs);
-        const double c = M - A;
-        b.cR[o] = M;
-        b.cM[o] = M;
-        b.cC[o] = c;
-        b.cV[o] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
-    } else {
-        b.cR[o] = (status == 1) ? b.g.a0 - 1 : bcash;  // what the generator is told (:595-599)
-        b.cM[o] = NAN;
+    b.cCnt[o] = r.cnt;
+    b.cSt[o] = r.status;
+    b.cR[o] = r.R;
+    b.cM[o] = r.M;
+    if (r.status == 0) {
+        b.cC[o] = r.C;
+        b.cV[o] = r.V;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// block-wide helpers (ENV_BS threads)
+// block-wide helpers (ENV_BS threads = ENV_BS/WAVE waves): wave-level ballot/shuffle first, one LDS exchange
+// across waves, two barriers per call
+#define ENV_NW (ENV_BS / WAVE)
 static __device__ __forceinline__ int blk_min(int v, int *sh)
 {
+    for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
     __syncthreads();
-    sh[threadIdx.x] = v;
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = v;
     __syncthreads();
-    for (int s = ENV_BS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = min(sh[threadIdx.x], sh[threadIdx.x + s]);
-        __syncthreads();
-    }
-    return sh[0];
+    int r = sh[0];
+    for (int w = 1; w < ENV_NW; w++) r = min(r, sh[w]);
+    return r;
 }
 static __device__ __forceinline__ int blk_sum(int v, int *sh)
 {
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
-    sh[threadIdx.x] = v;
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = v;
     __syncthreads();
-    for (int s = ENV_BS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    return sh[0];
+    int r = 0;
+    for (int w = 0; w < ENV_NW; w++) r += sh[w];
+    return r;
 }
-// exclusive scan of one flag per thread; returns the exclusive prefix, *total the block total
-static __device__ __forceinline__ int blk_scan(int v, int *sh, int *total)
+// exclusive scan of one 0/1 flag per thread; returns the exclusive prefix, *total the block total
+static __device__ __forceinline__ int blk_scan(int flag, int *sh, int *total)
 {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const unsigned long long mask = __ballot(flag != 0);
+    const int ex = __popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads();
-    sh[threadIdx.x] = v;
+    if (lane == 0) sh[wave] = __popcll(mask);
     __syncthreads();
-    for (int s = 1; s < ENV_BS; s <<= 1) {
-        int t = ((int)threadIdx.x >= s) ? sh[threadIdx.x - s] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < ENV_NW; w++) {
+        if (w < wave) off += sh[w];
+        tot += sh[w];
     }
-    *total = sh[ENV_BS - 1];
-    return sh[threadIdx.x] - v;
+    *total = tot;
+    return off + ex;
 }
 
 // strict order of comp1 (egdst_solver.c:1570-1582) extended by the original index (qsort of glibc is a
@@ -566,7 +676,7 @@ static __device__ __forceinline__ bool pt_before(double am, double av, int af, i
 // (om,oc,ov,of) and record rank[].  Each function's list is normally already ordered, so the rank of a point
 // is a sum of binary searches (a merge); an unordered list falls back to counting.
 static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const double *im, const double *ic, const double *iv, const int *ifn,
-                                     const int *fstart, const int *dims, double *om, double *oc, double *ov, int *of,
+                                     const eg_ldsi *fstart, const eg_ldsi *dims, double *om, double *oc, double *ov, int *of,
                                      int *rank, int *sh, int *oob, int *dbg)
 {
     int bad = 0;
@@ -647,6 +757,126 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-resident sort of the point stream (npts <= lcap).  Keys are staged in LDS first, so the binary searches
+// of the merge are LDS reads instead of dependent global loads.  When a list is out of comp1 order the whole
+// stream goes through a bitonic network instead (padded to a power of two); the per-function position lists
+// are then rebuilt from the sorted stream with one block scan per function.
+// Returns the position lists (rank[fstart[f]+k] = sorted position of the k-th point of f).
+static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const double *im, const double *ic,
+                                                        const double *iv, const int *ifn, const eg_ldsi *fstart,
+                                                        const eg_ldsi *dims, eg_ldsd *Km, eg_ldsd *Kv, eg_ldsd *Lm,
+                                                        eg_ldsd *Lc, eg_ldsd *Lv, eg_ldsi *Lf, eg_ldsi *Lp, int lcap,
+                                                        int *sh, int *oob)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npts; i += ENV_BS) {
+        Km[i] = im[i];
+        Kv[i] = iv[i];
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid + 1; i < npts; i += ENV_BS)
+        if (ifn[i] == ifn[i - 1] && !pt_before(Km[i - 1], Kv[i - 1], ifn[i - 1], i - 1, Km[i], Kv[i], ifn[i], i)) bad = 1;
+    bad = blk_sum(bad, sh);
+    int P = 1;
+    while (P < npts) P <<= 1;
+    if (bad && P > lcap) bad = 2;  // no room for the padded network: counting ranks instead
+    if (bad != 1) {
+        for (int i = tid; i < npts; i += ENV_BS) {
+            const double m = Km[i], v = Kv[i];
+            const int f = ifn[i];
+            int r = 0;
+            if (!bad) {
+                for (int g = 0; g < nf; g++) {
+                    const int dg = dims[g];
+                    if (dg <= 0) continue;
+                    const int s0 = fstart[g];
+                    if (g == f) {
+                        r += i - s0;
+                        continue;
+                    }
+                    int lo = 0, hi = dg;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    r += lo;
+                }
+            } else {
+                for (int j = 0; j < npts; j++)
+                    if (pt_before(Km[j], Kv[j], ifn[j], j, m, v, f, i)) r++;
+            }
+            if (r < 0 || r >= npts) {
+                *oob = 1;
+                continue;
+            }
+            Lp[i] = r;
+            Lm[r] = m;
+            Lv[r] = v;
+            Lc[r] = ic[i];
+            Lf[r] = f;
+        }
+        __syncthreads();
+        if (!bad) return Lp;
+    } else {
+        // bitonic network on (Km, Kv, Lf = function, Lp = input index); padding sorts last
+        for (int i = tid; i < P; i += ENV_BS) {
+            if (i < npts) {
+                Lf[i] = ifn[i];
+            } else {
+                Km[i] = INFINITY;
+                Kv[i] = -INFINITY;
+                Lf[i] = 0x7fffffff;
+            }
+            Lp[i] = i;
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += ENV_BS) {
+                    const int q = i ^ j;
+                    if (q > i) {
+                        const bool asc = (i & k) == 0;
+                        const bool qfirst = pt_before(Km[q], Kv[q], Lf[q], Lp[q], Km[i], Kv[i], Lf[i], Lp[i]);
+                        if (asc == qfirst) {  // ascending: q must not precede i; descending: the opposite
+                            const double tm = Km[i], tv = Kv[i];
+                            const int tf = Lf[i], tp = Lp[i];
+                            Km[i] = Km[q], Kv[i] = Kv[q], Lf[i] = Lf[q], Lp[i] = Lp[q];
+                            Km[q] = tm, Kv[q] = tv, Lf[q] = tf, Lp[q] = tp;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int r = tid; r < npts; r += ENV_BS) {
+            Lm[r] = Km[r];
+            Lv[r] = Kv[r];
+            Lc[r] = ic[Lp[r]];
+        }
+        __syncthreads();
+    }
+    // position lists from the sorted stream (the key buffer is free now)
+    eg_ldsi *posl = (eg_ldsi *)Km;
+    for (int g = 0; g < nf; g++) {
+        if (dims[g] <= 0) continue;
+        int carry = 0;
+        for (int base = 0; base < npts; base += ENV_BS) {
+            const int r = base + tid;
+            const int flag = (r < npts && Lf[r] == g);
+            int tot;
+            const int ex = blk_scan(flag, sh, &tot);
+            if (flag) posl[fstart[g] + carry + ex] = r;
+            carry += tot;
+        }
+    }
+    __syncthreads();
+    return posl;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stop rule, compaction, secondary and primary envelopes, output rows for one (draw, ist).
 #define ENV_FAIL(code)                                   \
     do {                                                 \
@@ -657,18 +887,77 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         return;                                          \
     } while (0)
 #ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
-#define EG_DYN_LDS(name) static double name[20480]
+#define EG_DYN_LDS(name) static double name[24576]
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
 #endif
-#define ENV_SMALLF 64
+#define ENV_SMALLF 256  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
-// lcap: sorted points that fit the dynamic LDS (5 arrays: M, C, V as doubles; function id and position list as ints)
+
+struct WalkJob {  // what one envelope walk needs besides the sorted stream
+    int it, ist, nf, npts, sec_id, ngridmax, nthrhmax, stackcap, cap;
+    double sec_ev;
+    eg_ldsi *fstart, *dims, *cur, *mark, *cnt;
+    const eg_ldsd *evfa0;
+    eg_ldsi *stack;
+    int *dbg;
+    double *og, *ov, *oc, *oth, *oix;
+};
+
+// wave 0 walks; returns through *err, *n, *m (every lane holds the same values)
+template <bool L>
+static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
+                                                const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
+                                                const typename EgMem<L>::I *f, const typename EgMem<L>::I *posl,
+                                                int *err, int *n, int *nth)
+{
+    EnvCtxT<L> e;
+    e.E = E;
+    e.it = j.it;
+    e.ist = j.ist;
+    e.nf = j.nf;
+    e.m = m;
+    e.c = c;
+    e.v = v;
+    e.f = f;
+    e.rank = posl;
+    e.fstart = j.fstart;
+    e.dims = j.dims;
+    e.cur = j.cur;
+    e.mark = j.mark;
+    e.cnt = j.cnt;
+    e.stack = j.stack;
+    e.stackcap = j.stackcap;
+    e.evfa0 = j.evfa0;
+    e.sec_id = j.sec_id;
+    e.sec_ev = j.sec_ev;
+    e.og = j.og;
+    e.ov = j.ov;
+    e.oc = j.oc;
+    e.oth = j.oth;
+    e.oix = j.oix;
+    e.ngridmax = j.ngridmax;
+    e.nthrhmax = j.nthrhmax;
+    e.cap = j.cap;
+    e.npts = j.npts;
+    e.dbg = j.dbg;
+    e.err = 0;
+    e.bound = 0;
+    e.ci = 0;
+    e.oi = e.oj = 0;
+    env_walk_wave(e, j.npts);
+    *err = e.err;
+    *n = e.oi;
+    *nth = e.oj;
+}
+
+// lcap: sorted points that fit the dynamic LDS (48 B each: staged keys, sorted M/C/V, function id, position list)
 __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal, int lcap)
 {
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_BS];
     __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
+    __shared__ int s_stack[2 * (ENV_SMALLF + 2)], s_fcnt[ENV_SMALLF];
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
@@ -697,313 +986,299 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     int *pF = b.pF + wo;
     double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
     int *sF = b.sF + wo;
-    int *rank = b.rank + wo;
-    const size_t fo = ((size_t)draw * MS_NST + ist) * (size_t)(ngridmax + MS_ND + 2);
-    int *gfstart = b.fstart + fo, *gfdims = b.fdims + fo, *gfcur = b.fcur + fo, *gfmark = b.fmark + fo;
-    double *Lm = dynlds, *Lc = Lm + lcap, *Lv = Lc + lcap;
-    int *Lf = (int *)(Lv + lcap), *Lr = Lf + lcap;
+    double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
+    int *qF = b.qF + wo, *rank = b.rank + wo;
     const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)ngridmax;
     double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eo, *eIX = b.eIX + eo;
-    int *stack = b.stack + 2 * eo;
-    // third buffer for sorted points: reuse the candidate arrays of this (draw, ist) -- they hold
-    // MS_ND*ngridmax entries; sorted input can reach (MS_ND+1)*ngridmax only in the secondary envelope of
-    // a single choice, where at most 2*ngridmax are live, so sorting goes to the `q` views below.
-    double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
-    int *qF = b.qF + wo;
+    double *oM = b.tM + tk * b.g.S, *oC = b.tC + tk * b.g.S, *oV = b.tV + tk * b.g.S;
+    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
+    // typed LDS views
+    eg_ldsd *Km = (eg_ldsd *)dynlds, *Kv = Km + lcap, *Lm = Kv + lcap, *Lc = Lm + lcap, *Lv = Lc + lcap;
+    eg_ldsi *Lf = (eg_ldsi *)(Lv + lcap), *Lr = Lf + lcap;
+    eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
 
+    WalkJob job;
+    job.it = it;
+    job.ist = ist;
+    job.ngridmax = ngridmax;
+    job.nthrhmax = b.g.nthrhmax;
+    job.stackcap = 2 * (ENV_SMALLF + 2);
+    job.cap = (int)W;
+    job.fstart = fstart;
+    job.dims = fdims;
+    job.cur = (eg_ldsi *)s_fcur;
+    job.mark = (eg_ldsi *)s_fmark;
+    job.cnt = (eg_ldsi *)s_fcnt;
+    job.evfa0 = (const eg_ldsd *)s_evfa0;
+    job.stack = (eg_ldsi *)s_stack;
+    job.dbg = b.dbg + 16 * draw;
+
+#ifdef EGDST_STAMPS  // diagnostic build: where does a workgroup spend its time (wall_clock64 ticks of 10 ns)
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (tid == 0) {                                                                            \
+            const unsigned long long now_ = wall_clock64();                                        \
+            atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 2 + (k), now_ - stamp_);        \
+            stamp_ = now_;                                                                         \
+        }                                                                                          \
+    } while (0)
+    unsigned long long stamp_ = wall_clock64();
+#else
+#define STAMP(k)
+#endif
     if (tid == 0) s_err = 0, s_oob = 0;
     __syncthreads();
-    int any = 0, nall = 0;
+    int any = 0, nall = 0, outn = 0, outm = 0, done = 0;
     unsigned long long evals = 0;
-    for (int id = 0; id < MS_ND; id++) {
-        __syncthreads();
-        if (tid == 0) {
-            s_cnt[id] = 0;
-            s_start[id] = nall;
-            s_evfa0[id] = 0.0;
-        }
-        const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
-        if (!P.active) continue;
-        any = 1;
-        const size_t co = eg_cand(b, draw, ist, id);
-        int nreq = 0;
-        double evfa0 = P.evfa0;
-        if (terminal) {
-            nreq = ngridm - 1;  // candidate indices 0..ngridm-1, all kept
-        } else if (P.seq) {
-            nreq = P.np - 1;    // k_fixup stored the kept points of the whole stream in order
-            evals += (unsigned long long)P.probe_evals;
-        } else {
-            const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
-            // first requested point whose returned M stops the stream (:1100): the point itself is kept
-            int first = navail + 1;
-            for (int n = 1 + tid; n <= navail; n += ENV_BS)
-                if (!(b.cR[co + n] < mmax)) {
-                    first = n;
-                    break;
-                }
-            first = blk_min(first, sh);
-            nreq = min(first, navail);
-            int hard = 0, n1 = 0, n2 = 0, ev = 0;
-            for (int n = 1 + tid; n <= nreq; n += ENV_BS) {
-                const int st = b.cSt[co + n];
-                if (st < 0) hard = max(hard, -st);
-                n1 += (st == 1);
-                n2 += (st == 2);
-                ev += b.cCnt[co + n];
-            }
-            hard = -blk_min(-hard, sh);
-            n1 = blk_sum(n1, sh);
-            n2 = blk_sum(n2, sh);
-            ev = blk_sum(ev, sh);
-            evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
-            if (hard) ENV_FAIL(hard);
-            if (n1) ENV_FAIL(26);  // c1<=0 inside the grid stage: the reference would resend from there
-            if (n2) evfa0 = -INFINITY;
-        }
-        // ---- compaction of kept points into the choice's list ----------------------------------
+    // jobs 0..MS_ND-1: the list of one choice (stop rule, compaction, secondary envelope when it folds back);
+    // job MS_ND: the primary envelope across choices.  Sorting and walking is ONE code site for all of them.
+    for (int jb = 0; jb <= MS_ND && !done; jb++) {
+        const bool primary = (jb == MS_ND);
+        const int id = jb;
+        const double *iM, *iC, *iV;
+        const int *iF;
         int cnt = 0;
-        {
-            int carry = 0;
-            for (int base = 0; base <= nreq; base += ENV_BS) {
-                const int n = base + tid;
-                int keepit = 0;
-                if (n <= nreq) {
-                    if (terminal || P.seq)
-                        keepit = 1;
-                    else if (n == 0)
-                        keepit = P.np;
-                    else
-                        keepit = (b.cSt[co + n] == 0 && isfinite(b.cM[co + n]));
-                }
-                int tot;
-                const int ex = blk_scan(keepit, sh, &tot);
-                if (keepit) {
-                    const int d = nall + carry + ex;
-                    if (d < 0 || (size_t)d >= W)
-                        s_oob = 1;
-                    else {
-                        pM[d] = b.cM[co + n];
-                        pC[d] = b.cC[co + n];
-                        pV[d] = b.cV[co + n];
-                        pF[d] = id;
-                    }
-                }
-                carry += tot;
+        double evfa0 = 0;
+        if (!primary) {
+            __syncthreads();
+            if (tid == 0) {
+                s_cnt[id] = 0;
+                s_start[id] = nall;
+                s_evfa0[id] = 0.0;
             }
-            cnt = carry;
-        }
-        __syncthreads();
-        if (s_oob) ENV_FAIL(2705);
-        // ---- secondary envelope (:776-913) ------------------------------------------------------
-        if (!terminal && cnt > 1) {
-            int nfold = 0;
-            for (int i = 1 + tid; i < cnt; i += ENV_BS)
-                if (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]) nfold++;
-            nfold = blk_sum(nfold, sh);
-            if (nfold > 0) {
-                const bool smallf = (id + nfold + 1) <= ENV_SMALLF;
-                int *fstart = smallf ? s_fstart : gfstart, *fdims = smallf ? s_fdims : gfdims;
-                int *fcur = smallf ? s_fcur : gfcur, *fmark = smallf ? s_fmark : gfmark;
-                // input with one constant-extrapolation point appended to every closed piece (:822-835)
-                int carry = 0, lastfold = 0;
-                for (int base = 0; base < cnt; base += ENV_BS) {
-                    const int i = base + tid;
-                    int fold = 0;
-                    if (i >= 1 && i < cnt)
-                        fold = (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]);
+            const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+            if (!P.active) continue;
+            any = 1;
+            const size_t co = eg_cand(b, draw, ist, id);
+            int nreq = 0;
+            evfa0 = P.evfa0;
+            if (terminal) {
+                nreq = ngridm - 1;  // candidate indices 0..ngridm-1, all kept
+            } else if (P.seq) {
+                nreq = P.np - 1;    // k_fixup stored the kept points of the whole stream in order
+                evals += (unsigned long long)P.probe_evals;
+            } else {
+                const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
+                // first requested point whose returned M stops the stream (:1100): the point itself is kept
+                int first = navail + 1;
+                for (int n = 1 + tid; n <= navail; n += ENV_BS)
+                    if (!(b.cR[co + n] < mmax)) {
+                        first = n;
+                        break;
+                    }
+                first = blk_min(first, sh);
+                nreq = min(first, navail);
+                int hard = 0, n1 = 0, n2 = 0, ev = 0;
+                for (int n = 1 + tid; n <= nreq; n += ENV_BS) {
+                    const int st = b.cSt[co + n];
+                    if (st < 0) hard = max(hard, -st);
+                    n1 += (st == 1);
+                    n2 += (st == 2);
+                    ev += b.cCnt[co + n];
+                }
+                hard = -blk_min(-hard, sh);
+                n1 = blk_sum(n1, sh);
+                n2 = blk_sum(n2, sh);
+                ev = blk_sum(ev, sh);
+                evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
+                if (hard) ENV_FAIL(hard);
+                if (n1) ENV_FAIL(26);  // k_fixup should have taken this stream over
+                if (n2) evfa0 = -INFINITY;
+            }
+            // ---- compaction of kept points into the choice's list ------------------------------
+            {
+                int carry = 0;
+                for (int base = 0; base <= nreq; base += ENV_BS) {
+                    const int n = base + tid;
+                    int keepit = 0;
+                    if (n <= nreq) {
+                        if (terminal || P.seq)
+                            keepit = 1;
+                        else if (n == 0)
+                            keepit = P.np;
+                        else
+                            keepit = (b.cSt[co + n] == 0 && isfinite(b.cM[co + n]));
+                    }
                     int tot;
-                    const int ex = blk_scan(fold, sh, &tot);
-                    if (i < cnt) {
-                        const int sidx = carry + ex + fold;  // pieces closed before this point
-                        const int d = i + sidx;
-                        if ((size_t)d >= W || id + sidx >= ngridmax + MS_ND + 2)
+                    const int ex = blk_scan(keepit, sh, &tot);
+                    if (keepit) {
+                        const int d = nall + carry + ex;
+                        if (d < 0 || (size_t)d >= W)
                             s_oob = 1;
                         else {
-                            sM[d] = pM[nall + i];
-                            sC[d] = pC[nall + i];
-                            sV[d] = pV[nall + i];
-                            sF[d] = id + sidx;
-                            if (fold) {
-                                sM[d - 1] = 1.5 * mmax;
-                                sC[d - 1] = pC[nall + i - 1];
-                                sV[d - 1] = pV[nall + i - 1];
-                                sF[d - 1] = id + sidx - 1;
-                                fstart[id + sidx] = d;
-                                if (sidx == nfold) lastfold = i;
-                            }
+                            pM[d] = b.cM[co + n];
+                            pC[d] = b.cC[co + n];
+                            pV[d] = b.cV[co + n];
+                            pF[d] = id;
                         }
-                        if (i == 0) fstart[id] = 0;
                     }
                     carry += tot;
                 }
-                lastfold = blk_sum(lastfold, sh);
-                if (s_oob) ENV_FAIL(2706);
-                const int total = cnt + nfold, nf = id + nfold + 1;
-                if (lastfold + (nfold - 1) >= ngridmax) ENV_FAIL(17);
-                if (id + nfold >= 10000) ENV_FAIL(18);
-                __syncthreads();
-                for (int f = tid; f < nf; f += ENV_BS) {
-                    if (f < id)
-                        fdims[f] = 0, fstart[f] = 0;
-                    else
-                        fdims[f] = ((f + 1 < nf) ? fstart[f + 1] : total) - fstart[f];
-                }
-                __syncthreads();
-                const bool inl = total <= lcap;  // sorted stream and position lists in LDS when they fit
-                double *zM = inl ? Lm : qM, *zC = inl ? Lc : qC, *zV = inl ? Lv : qV;
-                int *zF = inl ? Lf : qF, *zR = inl ? Lr : rank;
-                blk_rank_sort(total, nf, sM, sC, sV, sF, fstart, fdims, zM, zC, zV, zF, zR, sh, &s_oob, b.dbg + 16 * draw);
-                if (s_oob) ENV_FAIL(2704);
-                if (tid < WAVE) {  // wave 0 walks; every lane carries the same state
-                    EnvCtx e;
-                    e.E = &E;
-                    e.it = it;
-                    e.ist = ist;
-                    e.nf = nf;
-                    e.m = zM;
-                    e.c = zC;
-                    e.v = zV;
-                    e.f = zF;
-                    e.rank = zR;
-                    e.fstart = fstart;
-                    e.dims = fdims;
-                    e.cur = fcur;
-                    e.mark = fmark;
-                    e.stack = stack;
-                    e.stackcap = 2 * ngridmax;
-                    e.evfa0 = nullptr;
-                    e.sec_id = id;
-                    e.sec_ev = evfa0;
-                    e.og = eM;
-                    e.ov = eV;
-                    e.oc = eC;
-                    e.oth = eTH;
-                    e.oix = eIX;
-                    e.ngridmax = ngridmax;
-                    e.nthrhmax = b.g.nthrhmax;
-                    e.cap = (int)W;
-                    e.npts = total;
-                    e.dbg = b.dbg + 16 * draw;
-                    e.err = 0;
-                    env_walk_wave(e, total);
-                    if (!e.err && e.oi >= ngridmax) e.err = 17;  // (:884)
-                    s_err = e.err;
-                    s_n = e.oi;
-                }
-                __syncthreads();
-                if (s_err) ENV_FAIL(s_err);
-                cnt = s_n;
-                for (int i = tid; i < cnt; i += ENV_BS) {
-                    pM[nall + i] = eM[i];
-                    pC[nall + i] = eC[i];
-                    pV[nall + i] = eV[i];
-                    pF[nall + i] = id;
-                }
-                __syncthreads();
+                cnt = carry;
             }
-        }
-        if (tid == 0) {
-            s_cnt[id] = cnt;
-            s_evfa0[id] = evfa0;
-        }
-        nall += cnt;
-    }
-    __syncthreads();
-    if (!any) ENV_FAIL(14);
-    if (nall == 0) ENV_FAIL(15);
-    // ---- primary envelope across choices (:720, :1165-1550) ---------------------------------------
-    double *oM = b.tM + tk * b.g.S, *oC = b.tC + tk * b.g.S, *oV = b.tV + tk * b.g.S;
-    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
-    int nact = 0, fsingle = -1;
-    for (int id = 0; id < MS_ND; id++)
-        if (s_cnt[id] > 0) nact++, fsingle = id;
-    int outn = 0, outm = 0, done = 0;
-    if (nact == 1) {
-        // a single tabulated function: the walk keeps every point except repeats of a grid value,
-        // provided the list is already in comp1 order (it is unless M ties carry increasing V)
-        int bad = 0;
-        for (int i = 1 + tid; i < nall; i += ENV_BS)
-            if (pM[i - 1] > pM[i] || (pM[i - 1] == pM[i] && pV[i - 1] < pV[i])) bad = 1;
-        bad = blk_sum(bad, sh);
-        if (!bad) {
-            int carry = 0;
-            for (int base = 0; base < nall; base += ENV_BS) {
+            __syncthreads();
+            STAMP(0);  // stop rule + compaction
+            if (s_oob) ENV_FAIL(2705);
+            // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -----------
+            int nfold = 0;
+            if (!terminal && cnt > 1) {
+                for (int i = 1 + tid; i < cnt; i += ENV_BS)
+                    if (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]) nfold++;
+                nfold = blk_sum(nfold, sh);
+            }
+            if (nfold == 0) {
+                if (tid == 0) {
+                    s_cnt[id] = cnt;
+                    s_evfa0[id] = evfa0;
+                }
+                nall += cnt;
+                continue;
+            }
+            if (id + nfold + 1 > ENV_SMALLF) ENV_FAIL(2709);  // more monotone pieces than this build keeps in LDS
+            // input with one constant-extrapolation point appended to every closed piece (:822-835)
+            int carry = 0, lastfold = 0;
+            for (int base = 0; base < cnt; base += ENV_BS) {
                 const int i = base + tid;
-                const int keepit = (i < nall) && (i == 0 || pM[i] != pM[i - 1]);
+                int fold = 0;
+                if (i >= 1 && i < cnt) fold = (pM[nall + i - 1] > pM[nall + i] || pV[nall + i - 1] > pV[nall + i]);
                 int tot;
-                const int ex = blk_scan(keepit, sh, &tot);
-                if (keepit) {
-                    const int d = 1 + carry + ex;
-                    oM[d] = pM[i];
-                    oC[d] = pC[i];
-                    oV[d] = pV[i];
+                const int ex = blk_scan(fold, sh, &tot);
+                if (i < cnt) {
+                    const int sidx = carry + ex + fold;  // pieces closed before this point
+                    const int d = i + sidx;
+                    if ((size_t)d >= W || id + sidx >= ENV_SMALLF)
+                        s_oob = 1;
+                    else {
+                        sM[d] = pM[nall + i];
+                        sC[d] = pC[nall + i];
+                        sV[d] = pV[nall + i];
+                        sF[d] = id + sidx;
+                        if (fold) {
+                            sM[d - 1] = 1.5 * mmax;
+                            sC[d - 1] = pC[nall + i - 1];
+                            sV[d - 1] = pV[nall + i - 1];
+                            sF[d - 1] = id + sidx - 1;
+                            fstart[id + sidx] = d;
+                            if (sidx == nfold) lastfold = i;
+                        }
+                    }
+                    if (i == 0) fstart[id] = 0;
                 }
                 carry += tot;
             }
-            outn = carry;
-            outm = 1;
-            if (tid == 0) {
-                oTH[0] = b.g.a0;
-                oD[0] = fsingle;
+            lastfold = blk_sum(lastfold, sh);
+            if (s_oob) ENV_FAIL(2706);
+            if (lastfold + (nfold - 1) >= ngridmax) ENV_FAIL(17);
+            if (id + nfold >= 10000) ENV_FAIL(18);
+            job.npts = cnt + nfold;
+            job.nf = id + nfold + 1;
+            __syncthreads();
+            for (int f = tid; f < job.nf; f += ENV_BS) {
+                if (f < id)
+                    fdims[f] = 0, fstart[f] = 0;
+                else
+                    fdims[f] = ((f + 1 < job.nf) ? fstart[f + 1] : job.npts) - fstart[f];
             }
-            done = 1;
-            if (outn >= ngridmax || 1 >= b.g.nthrhmax) ENV_FAIL(outn >= ngridmax ? 13 : 20);
+            __syncthreads();
+            job.sec_id = id;
+            job.sec_ev = evfa0;
+            job.og = eM, job.ov = eV, job.oc = eC, job.oth = eTH, job.oix = eIX;
+            iM = sM, iC = sC, iV = sV, iF = sF;
+        } else {
+            __syncthreads();
+            if (!any) ENV_FAIL(14);
+            if (nall == 0) ENV_FAIL(15);
+            int nact = 0, fsingle = -1;
+            for (int k = 0; k < MS_ND; k++)
+                if (s_cnt[k] > 0) nact++, fsingle = k;
+            if (nact == 1) {
+                // a single tabulated function: the walk keeps every point except repeats of a grid value,
+                // provided the list is already in comp1 order (it is unless M ties carry increasing V)
+                int bad = 0;
+                for (int i = 1 + tid; i < nall; i += ENV_BS)
+                    if (pM[i - 1] > pM[i] || (pM[i - 1] == pM[i] && pV[i - 1] < pV[i])) bad = 1;
+                bad = blk_sum(bad, sh);
+                if (!bad) {
+                    int carry = 0;
+                    for (int base = 0; base < nall; base += ENV_BS) {
+                        const int i = base + tid;
+                        const int keepit = (i < nall) && (i == 0 || pM[i] != pM[i - 1]);
+                        int tot;
+                        const int ex = blk_scan(keepit, sh, &tot);
+                        if (keepit) {
+                            const int d = 1 + carry + ex;
+                            oM[d] = pM[i];
+                            oC[d] = pC[i];
+                            oV[d] = pV[i];
+                        }
+                        carry += tot;
+                    }
+                    outn = carry;
+                    outm = 1;
+                    if (tid == 0) {
+                        oTH[0] = b.g.a0;
+                        oD[0] = fsingle;
+                    }
+                    done = 1;
+                    if (outn >= ngridmax || 1 >= b.g.nthrhmax) ENV_FAIL(outn >= ngridmax ? 13 : 20);
+                    break;
+                }
+            }
+            for (int f = tid; f < MS_ND; f += ENV_BS) {
+                fstart[f] = s_start[f];
+                fdims[f] = s_cnt[f];
+            }
+            __syncthreads();
+            job.npts = nall;
+            job.nf = MS_ND;
+            job.sec_id = -1;
+            job.sec_ev = 0;
+            job.og = oM + 1, job.ov = oV + 1, job.oc = oC + 1, job.oth = oTH, job.oix = oD;
+            iM = pM, iC = pC, iV = pV, iF = pF;
         }
-    }
-    if (!done) {
-        int *fstart = s_fstart, *fdims = s_fdims, *fcur = s_fcur, *fmark = s_fmark;
-        const bool inl = nall <= lcap;
-        double *zM = inl ? Lm : qM, *zC = inl ? Lc : qC, *zV = inl ? Lv : qV;
-        int *zF = inl ? Lf : qF, *zR = inl ? Lr : rank;
-        for (int f = tid; f < MS_ND; f += ENV_BS) {
-            fstart[f] = s_start[f];
-            fdims[f] = s_cnt[f];
+        // ---- common: sort the stream (comp1 order) and walk it ----------------------------------------
+        if (job.npts <= lcap) {
+            const eg_ldsi *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, Km, Kv, Lm, Lc, Lv, Lf, Lr,
+                                               lcap, sh, &s_oob);
+            STAMP(3);  // LDS sort
+            if (s_oob) ENV_FAIL(2704);
+            if (tid < WAVE) {
+                int we, wn, wm;
+                run_walk<true>(&E, job, Lm, Lc, Lv, Lf, posl, &we, &wn, &wm);
+                s_err = we, s_n = wn, s_m = wm;
+            }
+        } else {
+            blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg);
+            if (s_oob) ENV_FAIL(2714);
+            if (tid < WAVE) {
+                int we, wn, wm;
+                run_walk<false>(&E, job, qM, qC, qV, qF, rank, &we, &wn, &wm);
+                s_err = we, s_n = wn, s_m = wm;
+            }
         }
         __syncthreads();
-        blk_rank_sort(nall, MS_ND, pM, pC, pV, pF, fstart, fdims, zM, zC, zV, zF, zR, sh, &s_oob, b.dbg + 16 * draw);
-        if (s_oob) ENV_FAIL(2714);
-        if (tid < WAVE) {  // wave 0 walks; every lane carries the same state
-            EnvCtx e;
-            e.E = &E;
-            e.it = it;
-            e.ist = ist;
-            e.nf = MS_ND;
-            e.m = zM;
-            e.c = zC;
-            e.v = zV;
-            e.f = zF;
-            e.rank = zR;
-            e.fstart = fstart;
-            e.dims = fdims;
-            e.cur = fcur;
-            e.mark = fmark;
-            e.stack = stack;
-            e.stackcap = 2 * ngridmax;
-            e.evfa0 = s_evfa0;
-            e.sec_id = -1;
-            e.sec_ev = 0;
-            e.og = oM + 1;
-            e.ov = oV + 1;
-            e.oc = oC + 1;
-            e.oth = oTH;
-            e.oix = oD;
-            e.ngridmax = ngridmax;
-            e.nthrhmax = b.g.nthrhmax;
-            e.cap = (int)W;
-            e.npts = nall;
-            e.dbg = b.dbg + 16 * draw;
-            e.err = 0;
-            env_walk_wave(e, nall);
-            if (!e.err && e.oi == 0) e.err = 16;
-            s_err = e.err;
-            s_n = e.oi;
-            s_m = e.oj;
-        }
-        __syncthreads();
+        STAMP(4);  // walk
         if (s_err) ENV_FAIL(s_err);
-        outn = s_n;
-        outm = s_m;
+        if (!primary) {
+            if (s_n >= ngridmax) ENV_FAIL(17);  // (:884)
+            cnt = s_n;
+            for (int i = tid; i < cnt; i += ENV_BS) {
+                pM[nall + i] = eM[i];
+                pC[nall + i] = eC[i];
+                pV[nall + i] = eV[i];
+                pF[nall + i] = id;
+            }
+            if (tid == 0) {
+                s_cnt[id] = cnt;
+                s_evfa0[id] = evfa0;
+            }
+            nall += cnt;
+            __syncthreads();
+        } else {
+            if (s_n == 0) ENV_FAIL(16);
+            outn = s_n;
+            outm = s_m;
+        }
     }
     // ---- row 0 and lengths (saveoutput :917-952; evf(a0) :730) ------------------------------------
     if (tid == 0) {

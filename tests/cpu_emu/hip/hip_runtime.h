@@ -50,6 +50,7 @@ static inline void __syncthreads()
 #if WAVE == 1
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_up(T v, int) { return v; }
+template <class T> static inline T __shfl_xor(T v, int) { return v; }
 static inline int __any(int x) { return x != 0; }
 static inline unsigned long long __ballot(int x) { return x ? 1ull : 0ull; }
 #else
@@ -91,6 +92,12 @@ template <class T> static inline T __shfl_up(T v, int d)
     emu_exchange(emu_pack(v), all);
     const int l = threadIdx.x % WAVE;
     return l >= d ? emu_unpack<T>(all[l - d]) : v;
+}
+template <class T> static inline T __shfl_xor(T v, int o)
+{
+    unsigned long long all[WAVE];
+    emu_exchange(emu_pack(v), all);
+    return emu_unpack<T>(all[(threadIdx.x % WAVE) ^ o]);
 }
 static inline unsigned long long __ballot(int x)
 {
