@@ -40,7 +40,7 @@ template <bool L> struct EnvCtxT {
     const typename EgMem<L>::I *rank;       // position lists
     const eg_ldsi *fstart;
     eg_ldsi *dims, *cur, *mark;
-    eg_ldsi *cnt;   // wave walk: points of each function at sorted positions before the current one
+    const typename EgMem<L>::I *cls;  // per sorted position: pre-classification word (env_preclass)
     eg_ldsi *stack;
     int stackcap;
     // expected value at a0 per function: primary -> evfa0[f]; secondary -> (f==sec_id ? sec_ev : -inf)
@@ -128,29 +128,44 @@ static __device__ __forceinline__ double env_sgn(double x) { return x > 0 ? 1.0 
 // brsolve (:1918-1968): bisection between an analytic value function `fa` and the segment (fl,kl)
 template <bool L> static __device__ __forceinline__ void env_bisect(EnvCtxT<L> &e, double *b0, double *b1, int fl, int kl, int fa)
 {
+    // The reference re-evaluates both bracket ends at every level of its recursion; they are pure functions of
+    // the bracket, so the values are carried along instead (bit-identical, a third of the evaluations).
+    // d[q] = analytic(b[q]) - segment(b[q]), a[q] = analytic(b[q]);  q = 0,1 the bracket ends, q = 2 the midpoint.
+    double bq[3] = {*b0, *b1, 0.0}, a[3], d[3];
+    int have = 0;  // ends already evaluated
     for (;;) {
-        double f0 = env_analytic(e, fa, *b0), f1 = env_analytic(e, fa, *b1);
-        double s0 = env_sgn(f0 - env_seg(e, fl, kl, *b0, 0)), s1 = env_sgn(f1 - env_seg(e, fl, kl, *b1, 0));
+        for (int q = have; q < 2; q++) {
+            a[q] = env_analytic(e, fa, bq[q]);
+            d[q] = a[q] - env_seg(e, fl, kl, bq[q], 0);
+        }
+        have = 2;
+        const double s0 = env_sgn(d[0]), s1 = env_sgn(d[1]);
         if (s0 == s1) {
             e.err = 22;
             return;
         }
-        if (*b0 > *b1) {
+        if (bq[0] > bq[1]) {
             e.err = 23;
             return;
         }
-        if (fabs(*b0 - *b1) < 2 * EG_DPD || fabs(f0 - f1) < EG_DPD) {
-            *b0 = (*b0 + *b1) / 2;
+        if (fabs(bq[0] - bq[1]) < 2 * EG_DPD || fabs(a[0] - a[1]) < EG_DPD) {
+            *b0 = (bq[0] + bq[1]) / 2;
+            *b1 = bq[1];
             return;
         }
-        double mid = (*b0 + *b1) / 2;
-        double sm = env_sgn(env_analytic(e, fa, mid) - env_seg(e, fl, kl, mid, 0));
+        bq[2] = (bq[0] + bq[1]) / 2;
+        a[2] = env_analytic(e, fa, bq[2]);
+        d[2] = a[2] - env_seg(e, fl, kl, bq[2], 0);
+        const double sm = env_sgn(d[2]);
         if (s0 == sm)
-            *b0 = mid;
+            bq[0] = bq[2], a[0] = a[2], d[0] = d[2];
         else if (s1 == sm)
-            *b1 = mid;
-        else
+            bq[1] = bq[2], a[1] = a[2], d[1] = d[2];
+        else {
+            *b0 = bq[0];
+            *b1 = bq[1];
             return;
+        }
     }
 }
 
@@ -169,28 +184,18 @@ template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L>
         e.mark[nwi] = 1;
         const int cp = e.cur[pri], cn = e.cur[nwi];
         double x = 0, top = 0;
-        if (cp == -1 && cn != -1) {
-            if (env_evf(e, pri) == -INFINITY)
-                x = e.m[env_at(e, pri, 0)];
+        if ((cp == -1) != (cn == -1)) {  // exactly one of the two is still in its analytic region (:1648-1688)
+            const int ana = (cp == -1) ? pri : nwi, lin = (cp == -1) ? nwi : pri, kl = (cp == -1) ? cn : cp;
+            if (env_evf(e, ana) == -INFINITY)
+                x = e.m[env_at(e, ana, 0)];
             else {
-                double br0 = e.m[env_at(e, nwi, cn)];
-                double br1 = MS_MIN(e.m[env_at(e, pri, 0)], e.m[env_at(e, nwi, cn + 1)]);
-                env_bisect(e, &br0, &br1, nwi, cn, pri);
+                double br0 = e.m[env_at(e, lin, kl)];
+                double br1 = MS_MIN(e.m[env_at(e, ana, 0)], e.m[env_at(e, lin, kl + 1)]);
+                env_bisect(e, &br0, &br1, lin, kl, ana);
                 if (e.err) return;
                 x = br0;
             }
-            top = env_seg(e, nwi, cn, x, 0);
-        } else if (cp != -1 && cn == -1) {
-            if (env_evf(e, nwi) == -INFINITY)
-                x = e.m[env_at(e, nwi, 0)];
-            else {
-                double br0 = e.m[env_at(e, pri, cp)];
-                double br1 = MS_MIN(e.m[env_at(e, nwi, 0)], e.m[env_at(e, pri, cp + 1)]);
-                env_bisect(e, &br0, &br1, pri, cp, nwi);
-                if (e.err) return;
-                x = br0;
-            }
-            top = env_seg(e, pri, cp, x, 0);
+            top = env_seg(e, lin, kl, x, 0);
         } else if (cp == -1 && cn == -1) {
             e.err = 21;
             return;
@@ -353,74 +358,79 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
                 return false;
             }
         }
-    } else if (e.pm == f) {  // point of the current max function (:1348-1416)
-        int above = 0, j;
-        double t;
-        for (j = 0; j < e.nf; j++) {
-            if (e.dims[j] <= 0 || j == f) continue;
-            t = env_fn(e, j, x);
-            if (fv < t) {
-                above = 1;
-                if (x != bound) break;
-                fv = t;
-                e.ci = j;
-            }
-        }
-        if (!above) {
-            env_push(e, x, fv, e.c[self]);
-            if (e.oi == e.ngridmax) {
-                e.err = 13;
-                return false;
-            }
-        } else if (x != bound) {
-            env_reset_marks(e);
-            env_crossing(e, f, j, 0);
-            if (e.err) return false;
-        } else {
-            env_reset_marks(e);
-            env_crossing(e, f, e.ci, 1);
-            if (e.err) return false;
-            e.lastg = x;
-            e.og[e.oi] = x;
-            e.ov[e.oi] = env_fn(e, e.ci, x);
-            // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
-            e.oc[e.oi] = (e.cur[e.ci] >= 0) ? env_seg(e, e.ci, e.cur[e.ci], x, 1) : x - a0;
-            e.oi++;
-            if (e.oi >= e.ngridmax) {
-                e.err = 13;
-                return false;
-            }
-        }
-    } else {  // point of another function (:1417-1516)
-        e.ci = e.pm;
-        double t = env_fn(e, e.ci, x);
-        if (t < fv) {
-            int cj = -1;
-            for (int j = 0; j < e.nf; j++) {
-                if (e.dims[j] <= 0 || j == f || j == e.ci) continue;
+    } else {
+        // Both remaining cases of the reference (:1348-1416 the point belongs to the current max function,
+        // :1417-1516 it belongs to another one) end in at most one thresholds() call followed by a small
+        // case-specific epilogue; the call is written once (code size: it inlines the whole crossing search).
+        int xa = -1, xb = -1, xmode = 0, post = 0;  // post: 0 nothing, 1 last row of ci, 2 push own point, 3 last row of cj
+        int cj = -1;
+        if (e.pm == f) {  // point of the current max function
+            int above = 0, j;
+            double t;
+            for (j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0 || j == f) continue;
                 t = env_fn(e, j, x);
-                if ((fv < t) || (fv == t && j < cj)) fv = t, cj = j;
+                if (fv < t) {
+                    above = 1;
+                    if (x != bound) break;
+                    fv = t;
+                    e.ci = j;
+                }
             }
+            if (!above) {
+                env_push(e, x, fv, e.c[self]);
+                if (e.oi == e.ngridmax) {
+                    e.err = 13;
+                    return false;
+                }
+            } else if (x != bound) {
+                xa = f, xb = j, xmode = 0, post = 0;
+            } else {
+                xa = f, xb = e.ci, xmode = 1, post = 1;
+            }
+        } else {  // point of another function
+            e.ci = e.pm;
+            double t = env_fn(e, e.ci, x);
+            if (t < fv) {
+                for (int j = 0; j < e.nf; j++) {
+                    if (e.dims[j] <= 0 || j == f || j == e.ci) continue;
+                    t = env_fn(e, j, x);
+                    if ((fv < t) || (fv == t && j < cj)) fv = t, cj = j;
+                }
+                if (cj == -1)
+                    xa = e.ci, xb = f, xmode = 1, post = 2;
+                else
+                    xa = e.ci, xb = cj, xmode = 1, post = (x == bound) ? 3 : 0;
+            } else if (x == bound) {
+                double vv = env_fn(e, e.ci, x), pp = env_policy(e, e.ci, x);
+                env_push(e, x, vv, pp);
+            }
+        }
+        if (xa >= 0) {
             env_reset_marks(e);
-            if (cj == -1) {
-                env_crossing(e, e.ci, f, 1);
-                if (e.err) return false;
+            env_crossing(e, xa, xb, xmode);
+            if (e.err) return false;
+            if (post == 1) {
+                e.lastg = x;
+                e.og[e.oi] = x;
+                e.ov[e.oi] = env_fn(e, e.ci, x);
+                // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
+                e.oc[e.oi] = (e.cur[e.ci] >= 0) ? env_seg(e, e.ci, e.cur[e.ci], x, 1) : x - a0;
+                e.oi++;
+                if (e.oi >= e.ngridmax) {
+                    e.err = 13;
+                    return false;
+                }
+            } else if (post == 2) {
                 env_push(e, x, fv, e.c[self]);
                 if (e.oi >= e.ngridmax) {
                     e.err = 13;
                     return false;
                 }
-            } else {
-                env_crossing(e, e.ci, cj, 1);
-                if (e.err) return false;
-                if (x == bound) {
-                    double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
-                    env_push(e, x, vv, pp);
-                }
+            } else if (post == 3) {
+                double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
+                env_push(e, x, vv, pp);
             }
-        } else if (x == bound) {
-            double vv = env_fn(e, e.ci, x), pp = env_policy(e, e.ci, x);
-            env_push(e, x, vv, pp);
         }
     }
     e.cur[f] = MS_MIN(e.cur[f] + 1, e.dims[f] - 2);
@@ -487,6 +497,49 @@ template <bool L> static __device__ __forceinline__ double env_fn_cnt(EnvCtxT<L>
     return env_analytic(e, j, x);
 }
 
+// Pre-classification of every sorted position by ALL threads of the workgroup (the floating-point part of the
+// walk).  For a grid value below the bound the walk's decision depends on its state only through the current
+// max function pm, so everything else is computed here, in parallel and state-free:
+//   bit 0      some other function is above this point (f == pm: the point is irregular, else kept)
+//   bit 1+j    function j is below this point          (f != pm: irregular iff bit 1+pm, else skipped)
+//   bit 30     no per-function bits (more than 29 functions): the scan evaluates f_pm(x) itself for f != pm
+//   sign bit   always irregular (at/after the bound, inconsistent stream)
+#define ENV_CLS_FORCE ((int)0x80000000)
+#define ENV_CLS_NOMASK (1 << 30)
+template <bool L>
+static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typename EgMem<L>::I *cls, int tid, int nthreads)
+{
+    double bound = INFINITY;
+    for (int f = 0; f < e.nf; f++)
+        if (e.dims[f] > 0) {
+            const double last = e.m[e.rank[e.fstart[f] + e.dims[f] - 1]];
+            if (last < bound) bound = last;
+        }
+    for (int p = tid; p < npts; p += nthreads) {
+        const int f = e.f[p];
+        const double x = e.m[p];
+        int w = 0;
+        if (!(x < bound) || f < 0 || f >= e.nf || e.dims[f] <= 0)
+            w = ENV_CLS_FORCE;
+        else {
+            const double fv = e.v[p];
+            for (int j = 0; j < e.nf; j++) {
+                if (e.dims[j] <= 0 || j == f) continue;
+                const int cj = env_count_before(e, j, p);
+                if (cj >= e.dims[j]) {  // cannot happen below the bound
+                    w = ENV_CLS_FORCE;
+                    break;
+                }
+                const double t = env_fn_cnt(e, j, cj, x);
+                if (fv < t) w |= 1;
+                if (t < fv && e.nf <= 29) w |= (2 << j);
+            }
+            if (e.nf > 29 && w >= 0) w |= ENV_CLS_NOMASK;
+        }
+        cls[p] = w;
+    }
+}
+
 // lane 0 takes one generic step; the few scalars the other lanes need are broadcast afterwards
 template <bool L> static __device__ __forceinline__ bool env_step_lane0(EnvCtxT<L> &e, int i, int lane, double *lastg, int *pm)
 {
@@ -527,7 +580,7 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
         e.lastg = -INFINITY;
         e.pm = -1;
         if (lane == 0)
-            for (int f = 0; f < e.nf; f++) e.cur[f] = -1, e.cnt[f] = 0;
+            for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
         e.err = __shfl(e.err, 0);
     }
     // phase 0: the first point(s) until a current-max function exists; phase 1: batches of EG_WAVE positions;
@@ -550,7 +603,7 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
             const unsigned long long vmask = __ballot(valid);
             if (!(vmask & 1ull)) {  // position i is at (or beyond) the bound: sequential tail with rebuilt cursors
                 if (lane == 0)
-                    for (int j = 0; j < e.nf; j++) e.cur[j] = e.cnt[j] - 1;
+                    for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
                 phase = 2;
                 continue;
             }
@@ -562,25 +615,16 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
                 x = e.m[p];
                 fv = e.v[p];
                 cc = e.c[p];
-                if (f < 0 || f >= e.nf || e.dims[f] <= 0)
-                    cls = 2;  // let env_step report the inconsistency
-                else
-                    cls = (f == pm) ? 0 : 1;
-            }
-            // One uniform pass over the functions: a ballot gives every lane the number of j-points that precede
-            // its position (no search), and the lanes that need f_j(x) evaluate it on j's current segment.
-            for (int j = 0; j < e.nf; j++) {
-                if (e.dims[j] <= 0) continue;
-                const unsigned long long mj = __ballot(valid && f == j);
-                if (valid && cls != 2 && j != f && (f == pm || j == pm)) {
-                    const int cj = e.cnt[j] + __popcll(mj & below);
-                    if (cj >= e.dims[j])
-                        cls = 2;  // cannot happen below the bound; the generic step sorts it out
-                    else {
-                        const double t = env_fn_cnt(e, j, cj, x);
-                        if (f == pm ? (fv < t) : (t < fv)) cls = 2;
-                    }
-                }
+                const int w = e.cls[p];
+                if (w < 0)
+                    cls = 2;
+                else if (f == pm)
+                    cls = (w & 1) ? 2 : 0;
+                else if (w & ENV_CLS_NOMASK) {
+                    const int cj = env_count_before(e, pm, p);
+                    cls = (cj >= e.dims[pm]) ? 2 : ((env_fn_cnt(e, pm, cj, x) < fv) ? 2 : 1);
+                } else
+                    cls = ((w >> (pm + 1)) & 1) ? 2 : 1;
             }
             // duplicates (:1290-1298): equal to the last kept grid value, carried in or kept earlier in this batch
             const double xprev = __shfl_up(x, 1);
@@ -613,27 +657,15 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
                 e.oi += nout;
                 lastg = __shfl(x, 63 - __clzll((long long)omask));  // grid value of the last point kept in this batch
             }
-            {   // the positions [i, i+stop) are done: advance the per-function counts
-                const unsigned long long done = (stop >= 64) ? ~0ull : ((1ull << stop) - 1ull);
-                for (int j = 0; j < e.nf; j++) {
-                    if (e.dims[j] <= 0) continue;
-                    const unsigned long long mj = __ballot(valid && f == j);
-                    if (lane == 0) e.cnt[j] += __popcll(mj & done);
-                }
-            }
             i += stop;
             step_now = stop < nvalid;
-            if (step_now) {  // irregular position: cursors for the generic step straight from the counts
+            if (step_now) {  // irregular position: rebuild the per-function cursors for the generic step
                 if (lane == 0)
-                    for (int j = 0; j < e.nf; j++) e.cur[j] = e.cnt[j] - 1;
+                    for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
             }
             WSTAMP(w_batch, w_nbatch);
         }
         if (step_now) {
-            if (lane == 0) {
-                const int fi = e.f[i];
-                if (fi >= 0 && fi < e.nf) e.cnt[fi] += 1;  // (position i is consumed by the step below)
-            }
             if (!env_step_lane0(e, i, lane, &lastg, &pm)) return;
             i++;
             if (phase == 0 && e.oj > 0) phase = 1;

@@ -887,7 +887,7 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
         return;                                          \
     } while (0)
 #ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
-#define EG_DYN_LDS(name) static double name[24576]
+#define EG_DYN_LDS(name) static double name[28672]
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
 #endif
@@ -897,19 +897,20 @@ static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookke
 struct WalkJob {  // what one envelope walk needs besides the sorted stream
     int it, ist, nf, npts, sec_id, ngridmax, nthrhmax, stackcap, cap;
     double sec_ev;
-    eg_ldsi *fstart, *dims, *cur, *mark, *cnt;
+    eg_ldsi *fstart, *dims, *cur, *mark;
     const eg_ldsd *evfa0;
     eg_ldsi *stack;
     int *dbg;
     double *og, *ov, *oc, *oth, *oix;
 };
 
-// wave 0 walks; returns through *err, *n, *m (every lane holds the same values)
+// All threads pre-classify the sorted stream, then wave 0 walks it; results through *err, *n, *nth (valid in wave 0,
+// every lane of it holds the same values)
 template <bool L>
 static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
                                                 const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
                                                 const typename EgMem<L>::I *f, const typename EgMem<L>::I *posl,
-                                                int *err, int *n, int *nth)
+                                                typename EgMem<L>::I *cls, int *err, int *n, int *nth)
 {
     EnvCtxT<L> e;
     e.E = E;
@@ -921,11 +922,11 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.v = v;
     e.f = f;
     e.rank = posl;
+    e.cls = cls;
     e.fstart = j.fstart;
     e.dims = j.dims;
     e.cur = j.cur;
     e.mark = j.mark;
-    e.cnt = j.cnt;
     e.stack = j.stack;
     e.stackcap = j.stackcap;
     e.evfa0 = j.evfa0;
@@ -945,10 +946,16 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.bound = 0;
     e.ci = 0;
     e.oi = e.oj = 0;
-    env_walk_wave(e, j.npts);
-    *err = e.err;
-    *n = e.oi;
-    *nth = e.oj;
+    e.lastg = 0;
+    e.pm = -1;
+    env_preclass(e, j.npts, cls, (int)threadIdx.x, ENV_BS);
+    __syncthreads();
+    if ((int)threadIdx.x < WAVE) {
+        env_walk_wave(e, j.npts);
+        *err = e.err;
+        *n = e.oi;
+        *nth = e.oj;
+    }
 }
 
 // lcap: sorted points that fit the dynamic LDS (48 B each: staged keys, sorted M/C/V, function id, position list)
@@ -957,7 +964,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_BS];
     __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
-    __shared__ int s_stack[2 * (ENV_SMALLF + 2)], s_fcnt[ENV_SMALLF];
+    __shared__ int s_stack[2 * (ENV_SMALLF + 2)];
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
@@ -994,7 +1001,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
     eg_ldsd *Km = (eg_ldsd *)dynlds, *Kv = Km + lcap, *Lm = Kv + lcap, *Lc = Lm + lcap, *Lv = Lc + lcap;
-    eg_ldsi *Lf = (eg_ldsi *)(Lv + lcap), *Lr = Lf + lcap;
+    eg_ldsi *Lf = (eg_ldsi *)(Lv + lcap), *Lr = Lf + lcap, *Lq = Lr + lcap;
     eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
 
     WalkJob job;
@@ -1008,7 +1015,6 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     job.dims = fdims;
     job.cur = (eg_ldsi *)s_fcur;
     job.mark = (eg_ldsi *)s_fmark;
-    job.cnt = (eg_ldsi *)s_fcnt;
     job.evfa0 = (const eg_ldsd *)s_evfa0;
     job.stack = (eg_ldsi *)s_stack;
     job.dbg = b.dbg + 16 * draw;
@@ -1242,18 +1248,18 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                                                lcap, sh, &s_oob);
             STAMP(3);  // LDS sort
             if (s_oob) ENV_FAIL(2704);
-            if (tid < WAVE) {
-                int we, wn, wm;
-                run_walk<true>(&E, job, Lm, Lc, Lv, Lf, posl, &we, &wn, &wm);
-                s_err = we, s_n = wn, s_m = wm;
+            {
+                int we = 0, wn = 0, wm = 0;
+                run_walk<true>(&E, job, Lm, Lc, Lv, Lf, posl, Lq, &we, &wn, &wm);
+                if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         } else {
             blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg);
             if (s_oob) ENV_FAIL(2714);
-            if (tid < WAVE) {
-                int we, wn, wm;
-                run_walk<false>(&E, job, qM, qC, qV, qF, rank, &we, &wn, &wm);
-                s_err = we, s_n = wn, s_m = wm;
+            {
+                int we = 0, wn = 0, wm = 0;  // (sF is free once the stream is sorted: it holds the classification words)
+                run_walk<false>(&E, job, qM, qC, qV, qF, rank, sF, &we, &wn, &wm);
+                if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         }
         __syncthreads();

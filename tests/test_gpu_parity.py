@@ -37,6 +37,8 @@ SCALED = {
     'C2': lambda: workloads.c2()[0],
     'C2_a0neg_T60': lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10),
     'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
+    # 3 x 1400 points do not fit the LDS stream buffers: exercises the global-memory sort and walk
+    'occ3_n1400_global_path': lambda: examples.occ3(T=12, ngridm=1400, ngridmax=14000, nthrhmax=1400, ny=10),
     'deaton_n4096': lambda: examples.deaton_sig(a0=0, mmax=50, t0=1, T=30, ngridm=4096, ngridmax=8192, ny=21),
 }
 
