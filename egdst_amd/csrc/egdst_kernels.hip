@@ -27,6 +27,9 @@
 #define ENV_BS 256
 #endif
 #define EG_WAVE WAVE
+#ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
+#define FIX_BS (8 * WAVE)
+#endif
 
 #include "egdst_device.h"
 #include "egdst_envelope.h"
@@ -314,9 +317,11 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
 //   full == 1 (k_fixup): keep going point by point to the end of the stream.  This is the exact sequential
 //            algorithm; it is used when a zero-consumption resend turns up INSIDE the grid stage
 //            (egdst_solver.c:1080-1099), which re-bases every later guess and cannot be speculated in parallel.
-static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, int draw, int ist, int id, int full)
+template <int NW, int full>
+static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, int draw, int ist, int id)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const bool lead = threadIdx.x == 0;  // all NW waves carry the same generator state; one thread writes
     ms_env E = eg_env(b, draw);
     ms_pv cur;
     cur.it = it;
@@ -326,7 +331,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     ProbeOut *P = &b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
     const int act = ms_feasible(&E, &cur) == 1 && ms_inchoiceset(&E, &cur) == 1;
     if (!act) {
-        if (lane == 0) P->active = 0;
+        if (lead) P->active = 0;
         return;
     }
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
@@ -356,7 +361,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 k3 = 0;
             } else {
                 if (last - a0 < EG_TOL) {
-                    if (lane == 0) eg_fail(b, draw, it, ist, 19);
+                    if (lead) eg_fail(b, draw, it, ist, 19);
                     return;
                 }
                 last = (last + a0) / 2;
@@ -400,8 +405,12 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 // or signals c1<=0 -- exactly the calls the reference would have made.
                 GridLims GL;
                 GL.lim1 = lim1, GL.lim2 = lim2, GL.lim3 = lim3, GL.lim3p = lim3p, GL.k3 = k3, GL.ntogenerate = ntogenerate;
-                const int n = ngenerated + lane;  // value of `ngenerated` at this lane's call
-                const bool can = n < ntogenerate && (ncalls + 1 + lane) < b.g.ngridmax;
+                __shared__ unsigned long long sx_can[NW], sx_hard[NW], sx_neg[NW], sx_stop[NW], sx_kept[NW], sx_inf[NW];
+                __shared__ int sx_hst[NW], sx_cnt[NW], sx_bist;
+                __shared__ double sx_take[2], sx_neg4[3];
+                const int gl = wave * WAVE + lane;  // position of this thread's guess in the batch
+                const int n = ngenerated + gl;      // value of `ngenerated` at this thread's call
+                const bool can = n < ntogenerate && (ncalls + 1 + gl) < b.g.ngridmax;
                 LaneEval r;
                 r.status = 0, r.cnt = 0, r.bist = 0, r.M = NAN, r.C = r.V = r.R = 0, r.bshock = r.bcash = 0;
                 double An = last;
@@ -409,58 +418,100 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                     An = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, n);
                     r = eg_lane_eval(b, &E, &cur, slot1, draw, An);
                 }
-                const unsigned long long canm = __ballot(can);
-                const unsigned long long hardm = __ballot(can && r.status < 0);
-                const unsigned long long negm = __ballot(can && r.status == 1);
-                const unsigned long long stopm = __ballot(can && r.status != 1 && !(r.R < mmax));
-                const int ncan = __popcll(canm);  // lanes [0, ncan) hold requested-if-reached guesses
-                const int fneg = negm ? __ffsll((long long)negm) - 1 : ncan;
-                const int fstop = stopm ? __ffsll((long long)stopm) - 1 : ncan;
-                // lanes [0, take) are consumed as ordinary calls; a stopping point is itself consumed
+                {   // phase 1: what every wave found, in batch order
+                    const unsigned long long canm = __ballot(can);
+                    const unsigned long long hardm = __ballot(can && r.status < 0);
+                    const unsigned long long negm = __ballot(can && r.status == 1);
+                    const unsigned long long stopm = __ballot(can && r.status != 1 && !(r.R < mmax));
+                    const int hst = __shfl(r.status, hardm ? __ffsll((long long)hardm) - 1 : 0);
+                    if (lane == 0) {
+                        sx_can[wave] = canm;
+                        sx_hard[wave] = hardm;
+                        sx_neg[wave] = negm;
+                        sx_stop[wave] = stopm;
+                        sx_hst[wave] = hst;
+                    }
+                }
+                __syncthreads();
+                int ncan = 0, fneg = -1, fstop = -1, fhard = -1, hcode = 0;
+                for (int w = 0; w < NW; w++) {  // threads [0, ncan) of the batch hold requested-if-reached guesses
+                    ncan += __popcll(sx_can[w]);
+                    if (fneg < 0 && sx_neg[w]) fneg = w * WAVE + __ffsll((long long)sx_neg[w]) - 1;
+                    if (fstop < 0 && sx_stop[w]) fstop = w * WAVE + __ffsll((long long)sx_stop[w]) - 1;
+                    if (fhard < 0 && sx_hard[w]) {
+                        fhard = w * WAVE + __ffsll((long long)sx_hard[w]) - 1;
+                        hcode = -sx_hst[w];
+                    }
+                }
+                if (fneg < 0) fneg = ncan;
+                if (fstop < 0) fstop = ncan;
+                // guesses [0, take) are consumed as ordinary calls; a stopping point is itself consumed
                 const int take = (fneg <= fstop) ? fneg : min(fstop + 1, ncan);
-                const unsigned long long takem = (take >= 64) ? ~0ull : ((1ull << take) - 1ull);
-                if (hardm & (takem | (fneg < ncan && fneg <= fstop ? (1ull << fneg) : 0ull))) {
-                    const int hl = __ffsll((long long)hardm) - 1;
-                    const int code = -__shfl(r.status, hl);
-                    if (lane == 0) eg_fail(b, draw, it, ist, code);
+                const bool negnext = fneg <= fstop && fneg < ncan;  // the call after them hits c1<=0
+                if (fhard >= 0 && (fhard < take || (negnext && fhard == fneg))) {
+                    if (lead) eg_fail(b, draw, it, ist, hcode);
                     return;
                 }
-                const bool kept = lane < take && r.status == 0 && isfinite(r.M);
-                const unsigned long long keptm = __ballot(kept);
-                const unsigned long long infm = __ballot(lane < take && r.status == 2);
-                if (np + __popcll(keptm) >= b.g.ngridmax - 1) {  // (:662)
-                    if (lane == 0) eg_fail(b, draw, it, ist, 13);
+                const bool kept = gl < take && r.status == 0 && isfinite(r.M);
+                {   // phase 2
+                    const unsigned long long keptm = __ballot(kept);
+                    const unsigned long long infm = __ballot(gl < take && r.status == 2);
+                    // evaluations of the consumed calls (and of the c1<=0 call, if it is next)
+                    int c = (gl < take || (negnext && gl == fneg)) ? r.cnt : 0;
+                    for (int o = WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                    if (lane == 0) {
+                        sx_kept[wave] = keptm;
+                        sx_inf[wave] = infm;
+                        sx_cnt[wave] = c;
+                    }
+                    if (take > 0 && gl == take - 1) {
+                        sx_take[0] = An;
+                        sx_take[1] = r.R;
+                    }
+                    if (negnext && gl == fneg) {
+                        sx_neg4[0] = An;
+                        sx_neg4[1] = r.bshock;
+                        sx_neg4[2] = r.bcash;
+                        sx_bist = r.bist;
+                    }
+                }
+                __syncthreads();
+                int nkept = 0, kbefore = 0, csum = 0;
+                bool anyinf = false;
+                for (int w = 0; w < NW; w++) {
+                    if (w < wave) kbefore += __popcll(sx_kept[w]);
+                    nkept += __popcll(sx_kept[w]);
+                    csum += sx_cnt[w];
+                    anyinf = anyinf || sx_inf[w] != 0;
+                }
+                if (np + nkept >= b.g.ngridmax - 1) {  // (:662)
+                    if (lead) eg_fail(b, draw, it, ist, 13);
                     return;
                 }
                 if (kept) {
-                    const size_t o = co + np + __popcll(keptm & ((1ull << lane) - 1ull));
+                    const size_t o = co + np + kbefore + __popcll(sx_kept[wave] & ((1ull << lane) - 1ull));
                     b.cM[o] = r.M;
                     b.cC[o] = r.C;
                     b.cV[o] = r.V;
                 }
-                np += __popcll(keptm);
-                if (infm) evfa0 = -INFINITY;
-                {   // evaluations of the consumed calls (and of the c1<=0 call, if it is next)
-                    int c = (lane < take || (fneg <= fstop && lane == fneg && fneg < ncan)) ? r.cnt : 0;
-                    for (int o = WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
-                    nev += c;
-                }
+                np += nkept;
+                if (anyinf) evfa0 = -INFINITY;
+                nev += csum;
                 if (take > 0) {
-                    last = __shfl(An, take - 1);
-                    M = __shfl(r.R, take - 1);
+                    last = sx_take[0];
+                    M = sx_take[1];
                     ngenerated += take;
                     ncalls += take;
                 }
                 keep = 1;
-                if (fneg <= fstop && fneg < ncan) {  // the next call hit c1<=0 (:583-621): prepare the resend
-                    const double An_ = __shfl(An, fneg);
+                if (negnext) {  // the next call hit c1<=0 (:583-621): prepare the resend
                     ms_pv nb;
                     nb.it = it + 1;
-                    nb.ist = __shfl(r.bist, fneg);
+                    nb.ist = sx_bist;
                     nb.id = 0;
-                    nb.shock = __shfl(r.bshock, fneg);
-                    nb.cash = __shfl(r.bcash, fneg);
-                    nb.savings = An_;
+                    nb.shock = sx_neg4[1];
+                    nb.cash = sx_neg4[2];
+                    nb.savings = sx_neg4[0];
                     const Tab tb = eg_tab(b, slot1, draw, nb.ist);
                     int ierr = 0;
                     ngenerated += 1;
@@ -469,7 +520,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                     M = a0 - 1;
                     last = eg_invert_budget(&E, cur, nb, (tb.V[0] > -INFINITY) ? a0 : tb.M[1], &ierr) + EG_ZEROC;
                     if (ierr) {
-                        if (lane == 0) eg_fail(b, draw, it, ist, ierr);
+                        if (lead) eg_fail(b, draw, it, ist, ierr);
                         return;
                     }
                 } else if (take == 0)
@@ -484,12 +535,12 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         double bshock = 0, bcash = 0;
         int st = eg_wave_expectation(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash);
         if (st < 0) {
-            if (lane == 0) eg_fail(b, draw, it, ist, -st);
+            if (lead) eg_fail(b, draw, it, ist, -st);
             return;
         }
         if (st > 0) {  // emergency (:583-627)
             if (ngenerated == 0) {
-                if (lane == 0) eg_fail(b, draw, it, ist, 12);
+                if (lead) eg_fail(b, draw, it, ist, 12);
                 return;
             }
             evfa0 = -INFINITY;
@@ -507,7 +558,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 M = a0 - 1;
                 last = eg_invert_budget(&E, cur, nb, (tb.V[0] > -INFINITY) ? a0 : tb.M[1], &ierr) + EG_ZEROC;
                 if (ierr) {
-                    if (lane == 0) eg_fail(b, draw, it, ist, ierr);
+                    if (lead) eg_fail(b, draw, it, ist, ierr);
                     return;
                 }
             }
@@ -518,10 +569,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         if (keep == 1 && isfinite(M)) {
             if (fabs(last - a0) < EG_TOL && evfa0 > -INFINITY) evfa0 = evf;
             if (np >= b.g.ngridmax - 1) {  // (:662)
-                if (lane == 0) eg_fail(b, draw, it, ist, 13);
+                if (lead) eg_fail(b, draw, it, ist, 13);
                 return;
             }
-            if (lane == 0) {
+            if (lead) {
                 const double c = M - last;
                 b.cM[co + np] = M;
                 b.cC[co + np] = c;
@@ -530,7 +581,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
             np += 1;  // full == 0: at most one kept point can precede the grid stage
         }
     }
-    if (lane == 0) {
+    if (lead) {
         P->active = 1;
         P->seq = full;
         P->np = np;
@@ -554,17 +605,17 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
     const int combo = blockIdx.x;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
     if (b.status[draw]) return;
-    eg_adraw_cycle(b, it, draw, ist, id, 0);
+    eg_adraw_cycle<1, 0>(b, it, draw, ist, id);
 }
 
 // After k_grid: does the stream of (draw, ist, id) contain a zero-consumption signal among the points the
 // generator would actually request?  If so redo that stream sequentially (exactly as the reference does).
-__global__ void __launch_bounds__(WAVE) k_fixup(Batch b, int it)
+__global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
 {
     const int combo = blockIdx.x;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
     if (b.status[draw]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);  // every wave of the workgroup takes the same decisions
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
     if (!P.active || !P.grid) return;
     const size_t co = eg_cand(b, draw, ist, id);
@@ -585,7 +636,10 @@ __global__ void __launch_bounds__(WAVE) k_fixup(Batch b, int it)
         if (resend || ms) break;
     }
     if (!resend) return;
-    eg_adraw_cycle(b, it, draw, ist, id, 1);
+#ifdef EGDST_EMU
+    if (threadIdx.x == 0 && getenv("EGDST_TRACE_FIXUP")) fprintf(stderr, "fixup it=%d draw=%d ist=%d id=%d\n", it, draw, ist, id);
+#endif
+    eg_adraw_cycle<FIX_BS / WAVE, 1>(b, it, draw, ist, id);
 }
 
 // ---------------------------------------------------------------------------------------------
