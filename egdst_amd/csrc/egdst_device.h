@@ -22,7 +22,11 @@
 
 // ---- problem geometry shared by all kernels -------------------------------------------------
 struct Geom {
-    int t0, T, nt, ngridm, ngridmax, nthrhmax, ny, ndraw, nslots, S;  // S = ngridmax+1 (row stride of a table)
+    int t0, T, nt, ngridm, ngridmax, nthrhmax, ny, ndraw, nslots, S;  // S = ngridmax+1 (logical rows of a table)
+    // PHYSICAL capacities of the device arrays.  Exact mode: Cp = ngridmax, Sp = S.  Compact mode
+    // (egdst_create_compact): Cp < ngridmax rows per list, so the arrays of many draws stay dense in memory; a
+    // draw that needs more rows than Cp stops with EGDST_E_CAPACITY and is solved again in exact mode by the host.
+    int Cp, Sp;
     double mmax, a0;
 };
 
@@ -33,27 +37,26 @@ struct Batch {
     const double *qw;    // [ny] weights
     const double *qz;    // [ny] standard-normal nodes (Acklam of the GL abscissae, egdst_solver.c:164)
     // period tables: index ((slot*ndraw+draw)*MS_NST+ist)
-    double *tM, *tC, *tV;   // * S
+    double *tM, *tC, *tV;   // * Sp
     double *tD, *tTH;       // * nthrhmax
     int *tlen, *tthlen;     // rows incl. the a0 row (0 = unsolved), thresholds
-    // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*ngridmax + n); n=0 is the probe's point
+    // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*Cp + n); n=0 is the probe's point
     double *cM, *cC, *cV, *cR;  // M, C, V, and the M returned to the guess generator
     int *cSt, *cCnt;            // status (0 normal, 1 c1<=0, 2 evf=-inf), evaluations done for the point
     struct ProbeOut *probe;     // [(draw*MS_NST+ist)*MS_ND+id]
-    // envelope workspaces per (draw,ist): W = (MS_ND+1)*ngridmax entries
+    // envelope workspaces per (draw,ist): W = (MS_ND+1)*Cp entries
     double *pM, *pC, *pV;  int *pF;    // per-choice lists, consecutive (the reference's mgridvecs)
     double *sM, *sC, *sV;  int *sF;    // secondary-envelope input (pieces with their extrapolation points)
     double *qM, *qC, *qV;  int *qF;    // points sorted in comp1 order
     int *rank;                          // [W] sorted position of each input point
-    int *fstart, *fdims, *fcur, *fmark; // [ngridmax+MS_ND+2] per-function bookkeeping
-    double *eM, *eV, *eC;               // [ngridmax] output of a secondary envelope
-    double *eTH, *eIX;                  // [ngridmax]
-    int *stack;                         // [2*ngridmax] pending crossings
+    double *eM, *eV, *eC;               // [Cp] output of a secondary envelope
+    double *eTH, *eIX;                  // [Cp]
     // status
     int *status;          // [ndraw] first error code
     int *where;           // [2*ndraw] (it, ist) of that error
     unsigned long long *evals;  // [ndraw]
     int *dbg;             // [16*ndraw] diagnostics of a tripped internal guard
+    double *obj;          // [2*ndraw] staging of k_objective for the host-returning entry point
     unsigned long long *algbytes;  // [ndraw] compulsory table traffic: 24 B per next-period row read once per
                                    // period + 24 B per row written + 16 B per threshold
 };
@@ -161,9 +164,9 @@ static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw,
 {
     size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
     Tab t;
-    t.M = b.tM + k * b.g.S;
-    t.C = b.tC + k * b.g.S;
-    t.V = b.tV + k * b.g.S;
+    t.M = b.tM + k * b.g.Sp;
+    t.C = b.tC + k * b.g.Sp;
+    t.V = b.tV + k * b.g.Sp;
     t.TH = b.tTH + k * b.g.nthrhmax;
     t.D = b.tD + k * b.g.nthrhmax;
     t.len = b.tlen[k];

@@ -48,7 +48,7 @@ template <bool L> struct EnvCtxT {
     int sec_id;
     double sec_ev;
     double *og, *ov, *oc, *oth, *oix;
-    int oi, oj, ngridmax, nthrhmax;
+    int oi, oj, ocap, e13, nthrhmax;  // ocap rows fit the output; filling it is error e13 (13, or CAPACITY when ocap is physical)
     int cap, npts;  // capacity of rank[] and number of sorted points (bounds guard)
     double bound;   // min over functions of the last grid point
     double lastg;   // grid value of the last output row (og[oi-1]); kept in a register so the walk never reads og back
@@ -257,8 +257,8 @@ template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L>
         e.pm = nwi;
         e.oi += 1;
         e.oj += 1;
-        if (e.oi >= e.ngridmax) {
-            e.err = 13;
+        if (e.oi >= e.ocap) {
+            e.err = e.e13;
             return;
         }
         if (e.oj >= e.nthrhmax) {
@@ -276,8 +276,8 @@ template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L>
             e.ov[e.oi] = top;
             e.oc[e.oi] = pol1;
             e.oi += 1;
-            if (e.oi >= e.ngridmax) {
-                e.err = 13;
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
                 return;
             }
         }
@@ -353,8 +353,8 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
         }
         if (e.ci == f) {
             env_push(e, x, t, e.c[self]);
-            if (e.oi >= e.ngridmax) {
-                e.err = 13;
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
                 return false;
             }
         }
@@ -379,8 +379,8 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
             }
             if (!above) {
                 env_push(e, x, fv, e.c[self]);
-                if (e.oi == e.ngridmax) {
-                    e.err = 13;
+                if (e.oi == e.ocap) {
+                    e.err = e.e13;
                     return false;
                 }
             } else if (x != bound) {
@@ -417,14 +417,14 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
                 // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
                 e.oc[e.oi] = (e.cur[e.ci] >= 0) ? env_seg(e, e.ci, e.cur[e.ci], x, 1) : x - a0;
                 e.oi++;
-                if (e.oi >= e.ngridmax) {
-                    e.err = 13;
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
                     return false;
                 }
             } else if (post == 2) {
                 env_push(e, x, fv, e.c[self]);
-                if (e.oi >= e.ngridmax) {
-                    e.err = 13;
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
                     return false;
                 }
             } else if (post == 3) {
@@ -644,8 +644,8 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
             const unsigned long long omask = __ballot(out);
             const int nout = __popcll(omask);
             if (nout) {
-                if (e.oi + nout >= e.ngridmax) {  // the push that fills the grid is an error in the reference (:1378)
-                    e.err = 13;
+                if (e.oi + nout >= e.ocap) {  // the push that fills the grid is an error in the reference (:1378)
+                    e.err = e.e13;
                     return;
                 }
                 if (out) {

@@ -61,7 +61,7 @@ static __device__ __forceinline__ ms_env eg_env(const Batch &b, int draw)
 
 static __device__ __forceinline__ size_t eg_cand(const Batch &b, int draw, int ist, int id)
 {
-    return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.ngridmax;
+    return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.Cp;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -169,7 +169,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
             status = -10;
             break;
         }
-        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) {
+        if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) {
             status = -2707;
             break;
         }
@@ -256,7 +256,7 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
         const int niy = (ms_sigma(E, cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
         const Tab t = eg_tab(b, slot1, draw, ist1);
         if (t.len < 2) return -10;
-        if (t.len > b.g.S || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
+        if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
         for (int base = 0; base < niy && status == 0; base += WAVE) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
@@ -488,6 +488,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                     if (lead) eg_fail(b, draw, it, ist, 13);
                     return;
                 }
+                if (np + nkept > b.g.Cp) {
+                    if (lead) eg_fail(b, draw, it, ist, EGDST_E_CAPACITY);
+                    return;
+                }
                 if (kept) {
                     const size_t o = co + np + kbefore + __popcll(sx_kept[wave] & ((1ull << lane) - 1ull));
                     b.cM[o] = r.M;
@@ -570,6 +574,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
             if (fabs(last - a0) < EG_TOL && evfa0 > -INFINITY) evfa0 = evf;
             if (np >= b.g.ngridmax - 1) {  // (:662)
                 if (lead) eg_fail(b, draw, it, ist, 13);
+                return;
+            }
+            if (np >= b.g.Cp) {
+                if (lead) eg_fail(b, draw, it, ist, EGDST_E_CAPACITY);
                 return;
             }
             if (lead) {
@@ -949,7 +957,7 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
 
 struct WalkJob {  // what one envelope walk needs besides the sorted stream
-    int it, ist, nf, npts, sec_id, ngridmax, nthrhmax, stackcap, cap;
+    int it, ist, nf, npts, sec_id, ocap, e13, nthrhmax, stackcap, cap;
     double sec_ev;
     eg_ldsi *fstart, *dims, *cur, *mark;
     const eg_ldsd *evfa0;
@@ -991,7 +999,8 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.oc = j.oc;
     e.oth = j.oth;
     e.oix = j.oix;
-    e.ngridmax = j.ngridmax;
+    e.ocap = j.ocap;
+    e.e13 = j.e13;
     e.nthrhmax = j.nthrhmax;
     e.cap = j.cap;
     e.npts = j.npts;
@@ -1042,16 +1051,18 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     }
     const int ngridmax = b.g.ngridmax, ngridm = b.g.ngridm;
     const double mmax = b.g.mmax;
-    const size_t W = (size_t)(MS_ND + 1) * ngridmax, wo = ((size_t)draw * MS_NST + ist) * W;
+    const int compact = b.g.Cp < ngridmax;  // physical capacity below the logical one: overflow = EGDST_E_CAPACITY
+    const size_t W = (size_t)(MS_ND + 1) * b.g.Cp, wo = ((size_t)draw * MS_NST + ist) * W;
     double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
     int *pF = b.pF + wo;
     double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
     int *sF = b.sF + wo;
     double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
     int *qF = b.qF + wo, *rank = b.rank + wo;
-    const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)ngridmax;
-    double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eo, *eIX = b.eIX + eo;
-    double *oM = b.tM + tk * b.g.S, *oC = b.tC + tk * b.g.S, *oV = b.tV + tk * b.g.S;
+    const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)b.g.Cp;
+    const size_t eto = ((size_t)draw * MS_NST + ist) * (size_t)b.g.nthrhmax;
+    double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eto, *eIX = b.eIX + eto;
+    double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
     eg_ldsd *Km = (eg_ldsd *)dynlds, *Kv = Km + lcap, *Lm = Kv + lcap, *Lc = Lm + lcap, *Lv = Lc + lcap;
@@ -1061,7 +1072,8 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     WalkJob job;
     job.it = it;
     job.ist = ist;
-    job.ngridmax = ngridmax;
+    job.ocap = b.g.Cp;  // rows of a secondary output (eM..) and of a table without its a0 row
+    job.e13 = compact ? EGDST_E_CAPACITY : 13;
     job.nthrhmax = b.g.nthrhmax;
     job.stackcap = 2 * (ENV_SMALLF + 2);
     job.cap = (int)W;
@@ -1178,7 +1190,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
             }
             __syncthreads();
             STAMP(0);  // stop rule + compaction
-            if (s_oob) ENV_FAIL(2705);
+            if (s_oob) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2705);
             // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -----------
             int nfold = 0;
             if (!terminal && cnt > 1) {
@@ -1227,7 +1239,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                 carry += tot;
             }
             lastfold = blk_sum(lastfold, sh);
-            if (s_oob) ENV_FAIL(2706);
+            if (s_oob) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2706);
             if (lastfold + (nfold - 1) >= ngridmax) ENV_FAIL(17);
             if (id + nfold >= 10000) ENV_FAIL(18);
             job.npts = cnt + nfold;
@@ -1259,6 +1271,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
                     if (pM[i - 1] > pM[i] || (pM[i - 1] == pM[i] && pV[i - 1] < pV[i])) bad = 1;
                 bad = blk_sum(bad, sh);
                 if (!bad) {
+                    if (nall > b.g.Cp) ENV_FAIL(compact ? EGDST_E_CAPACITY : 13);
                     int carry = 0;
                     for (int base = 0; base < nall; base += ENV_BS) {
                         const int i = base + tid;
@@ -1322,6 +1335,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         if (!primary) {
             if (s_n >= ngridmax) ENV_FAIL(17);  // (:884)
             cnt = s_n;
+            if ((size_t)(nall + cnt) > W) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2705);
             for (int i = tid; i < cnt; i += ENV_BS) {
                 pM[nall + i] = eM[i];
                 pC[nall + i] = eC[i];
@@ -1482,8 +1496,8 @@ __global__ void k_objective(Batch b, double *out)
     const int slot = (b.g.nslots == 2) ? 0 : 0;
     const size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST;
     const bool ok = b.status[draw] == 0 && b.tlen[k] >= 2;
-    out[2 * draw] = ok ? b.tV[k * b.g.S + 1] : NAN;
-    out[2 * draw + 1] = ok ? b.tC[k * b.g.S + 1] : NAN;
+    out[2 * draw] = ok ? b.tV[k * b.g.Sp + 1] : NAN;
+    out[2 * draw + 1] = ok ? b.tC[k * b.g.Sp + 1] : NAN;
 }
 
 #include "egdst_host.inc"

@@ -30,7 +30,8 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_set_params', 'egdst_set_params_dev', 'egdst_solve_async', 'egdst_sync', 'egdst_solve',
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
-               'egdst_get_profile', 'egdst_objective_dev']
+               'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
+               'egdst_create_compact', 'egdst_geometry']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -61,6 +62,11 @@ class ModelLibrary:
         L.egdst_strerror.restype = C.c_char_p
         L.egdst_last_error.restype = C.c_char_p
         L.egdst_create.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.egdst_create_compact.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_void_p)]
+        L.egdst_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.egdst_get_objective.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.egdst_get_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.egdst_destroy.argtypes = [C.c_void_p]
         L.egdst_set_params.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.egdst_set_params_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -127,9 +133,16 @@ class Solution:
 
 
 class Solver:
-    """A device-resident batch of `ndraw` independent solves of one compiled model."""
+    """A device-resident batch of `ndraw` independent solves of one compiled model.
 
-    def __init__(self, lib: ModelLibrary, desc: dict, ndraw=1, keep_history=True, stream=None):
+    rows_cap > 0 makes the handle COMPACT (include/egdst.h: egdst_create_compact): device lists and tables hold
+    rows_cap rows instead of ngridmax, which keeps thousands of resident draws dense in memory.  A draw that needs
+    more rows stops with EGDST_E_CAPACITY on the device; `sync` then solves exactly those draws again on a second,
+    exact handle and every accessor below answers for them from there, so callers see the reference's semantics.
+    """
+    E_CAPACITY = 28
+
+    def __init__(self, lib: ModelLibrary, desc: dict, ndraw=1, keep_history=True, stream=None, rows_cap=0):
         self.lib, self.ndraw, self.keep_history = lib, int(ndraw), bool(keep_history)
         self._quad = np.ascontiguousarray(desc['quadrature'], dtype=np.float64)
         ngridmax = desc['ngridmax'] if desc['ngridmax'] > desc['ngridm'] else 2 * desc['ngridm']
@@ -138,10 +151,17 @@ class Solver:
                       desc['mmax'], desc['a0'], _dp(self._quad))
         self.nt = desc['T'] - desc['t0'] + 1
         self.h = C.c_void_p()
-        lib.check(lib.lib.egdst_create(C.byref(d), self.ndraw, int(self.keep_history),
-                                       C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.rows_cap = int(rows_cap) if 0 < int(rows_cap) < ngridmax else 0
+        self._exact = None          # exact handle for the draws that overflowed the compact one
+        self._redo = np.zeros(0, dtype=np.int64)   # their draw indices, in the order of self._exact
+        self.capacity_retries = 0   # draws solved again since creation
+        lib.check(lib.lib.egdst_create_compact(C.byref(d), self.ndraw, int(self.keep_history), self.rows_cap,
+                                               C.c_void_p(stream) if stream else None, C.byref(self.h)))
 
     def close(self):
+        if self._exact is not None:
+            self._exact.close()
+            self._exact = None
         if self.h:
             self.lib.lib.egdst_destroy(self.h)
             self.h = C.c_void_p()
@@ -151,6 +171,20 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+    def geometry(self):
+        """(physical rows per list, row stride of the device tables)"""
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.lib.egdst_geometry(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def _route(self, draw):
+        """(solver, local draw) that holds the results of `draw`"""
+        if len(self._redo):
+            j = np.nonzero(self._redo == draw)[0]
+            if len(j):
+                return self._exact, int(j[0])
+        return self, draw
 
     def set_params(self, params):
         p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(self.ndraw, -1))
@@ -166,27 +200,71 @@ class Solver:
 
     def sync(self, raise_on_error=True):
         rc = self.lib.lib.egdst_sync(self.h)
+        self._redo = np.zeros(0, dtype=np.int64)
+        if rc and self.rows_cap:
+            rc = self._redo_overflowed()
         if rc and (raise_on_error or rc < 10):
             self.lib.check(rc)
         return rc
+
+    def _redo_overflowed(self):
+        """Solve the draws that stopped with EGDST_E_CAPACITY again with exact capacities; returns the first
+        non-zero per-draw status of the batch after that (what egdst_sync would have returned)."""
+        st, _ = self._status_raw()
+        idx = np.nonzero(st == self.E_CAPACITY)[0]
+        if len(idx):
+            par = np.zeros((self.ndraw, max(self.lib.info.nparam, 1)))
+            self.lib.check(self.lib.lib.egdst_get_params(self.h, _dp(par)))
+            if self._exact is None or self._exact.ndraw != len(idx):
+                if self._exact is not None:
+                    self._exact.close()
+                self._exact = Solver(self.lib, self.desc, ndraw=len(idx), keep_history=self.keep_history)
+            self._exact.set_params(par[idx, :self.lib.info.nparam])
+            self._exact.solve(raise_on_error=False)
+            self._redo = idx.astype(np.int64)
+            self.capacity_retries += len(idx)
+        st, _ = self.status()
+        bad = st[st != 0]
+        return int(bad[0]) if len(bad) else 0
 
     def solve(self, raise_on_error=True):
         self.solve_async()
         return self.sync(raise_on_error)
 
-    def status(self):
+    def _status_raw(self):
         st = np.zeros(self.ndraw, dtype=np.int32)
         wh = np.zeros(2 * self.ndraw, dtype=np.int32)
         self.lib.check(self.lib.lib.egdst_get_status(self.h, _ip(st), _ip(wh)))
         return st, wh.reshape(self.ndraw, 2)
 
+    def status(self):
+        st, wh = self._status_raw()
+        if len(self._redo):
+            st[self._redo], wh[self._redo] = self._exact.status()
+        return st, wh
+
     def evals(self):
         tot = C.c_longlong(0)
         per = np.zeros(self.ndraw, dtype=np.int64)
         self.lib.check(self.lib.lib.egdst_get_evals(self.h, C.byref(tot), per.ctypes.data_as(C.POINTER(C.c_longlong))))
+        if len(self._redo):
+            per[self._redo] = self._exact.evals()[1]
+            return int(per.sum()), per
         return int(tot.value), per
 
+    def objective(self):
+        """[ndraw, 2] host array of the objective contributions (egdst_objective_dev), NaN for failed draws."""
+        out = np.zeros((self.ndraw, 2))
+        self.lib.check(self.lib.lib.egdst_get_objective(self.h, _dp(out)))
+        if len(self._redo):
+            out[self._redo] = self._exact.objective()
+        return out
+
     def solution(self, draw=0):
+        if len(self._redo):
+            s_, j_ = self._route(draw)
+            if s_ is not self:
+                return s_.solution(j_)
         d = self.desc
         sol = Solution(self.nt, self.lib.info.nst, d['ngridmax'], d['nthrhmax'])
         self.lib.check(self.lib.lib.egdst_get_solution(self.h, draw, _ip(sol.len), _ip(sol.thlen), _dp(sol.M),
@@ -198,6 +276,8 @@ class Solver:
         return sol
 
     def objective_dev(self, dev_ptr):
+        """Device-side objective of THIS handle's draws (draws redone after a capacity overflow read NaN here;
+        use objective() when rows_cap is set and capacity_retries may be non-zero)."""
         self.lib.check(self.lib.lib.egdst_objective_dev(self.h, C.c_void_p(dev_ptr)))
 
     def set_profile(self, on=True):
@@ -217,6 +297,9 @@ class Solver:
         return out
 
     def cell_M(self, draw, it, ist):
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.cell_M(j_, it, ist)
         n, nth = C.c_int(0), C.c_int(0)
         self.lib.check(self.lib.lib.egdst_cell_dims(self.h, draw, it, ist, C.byref(n), C.byref(nth)))
         out = np.zeros((4, n.value))
@@ -225,6 +308,9 @@ class Solver:
         return np.ascontiguousarray(out.T)  # column-major (len x 4) -> rows
 
     def cell_D(self, draw, it, ist):
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.cell_D(j_, it, ist)
         n, nth = C.c_int(0), C.c_int(0)
         self.lib.check(self.lib.lib.egdst_cell_dims(self.h, draw, it, ist, C.byref(n), C.byref(nth)))
         out = np.zeros((2, nth.value))
@@ -233,6 +319,9 @@ class Solver:
         return np.ascontiguousarray(out.T)
 
     def simulate(self, init, randstream, rndtype=0, draw=0):
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.simulate(init, randstream, rndtype, j_)
         init = np.asfortranarray(np.atleast_2d(np.asarray(init, dtype=np.float64)))
         nsim = init.shape[0]
         info = self.lib.info

@@ -66,9 +66,11 @@ enum {
     EGDST_E_BRACKET_REV = 23,   /* egdst_solver.c:1943 */
     EGDST_E_BUDGET_INVERT = 24, /* egdst_lib.c:293 */
     EGDST_E_TRPR_CASES = 25,    /* compile.m:541-544 */
-    EGDST_E_RESEND_IN_GRID = 26,/* c1<=0 after the first kept grid point (egdst_solver.c:1080-1099 reached
-                                   from the parallel grid stage): not supported by this build, fails loudly */
+    EGDST_E_RESEND_IN_GRID = 26,/* internal guard: a c1<=0 resend inside the grid stage (egdst_solver.c:1080-1099)
+                                   reached the envelope without having been redone sequentially by k_fixup */
     EGDST_E_INTERNAL = 27,      /* scratch exhausted (crossing stack) */
+    EGDST_E_CAPACITY = 28,      /* compact handles only: the draw needs more rows than rows_cap (no reference
+                                   counterpart; solve the draw again with exact capacities) */
     /* simulator gateway (egdst_simulator.c:54-75,155,165) */
     EGDST_E_NOT_SOLVED = 40,
     EGDST_E_RAND_SHORT = 41,
@@ -83,12 +85,23 @@ const char *egdst_last_error(void);
  * tables resident (needed for cell export and simulation); 0 keeps two ping-pong periods only.
  * stream: a hipStream_t (NULL = the library creates its own non-blocking stream). */
 int egdst_create(const egdst_desc *desc, int ndraw, int keep_history, void *stream, egdst_handle **out);
+/* The same with PHYSICAL row capacity rows_cap < ngridmax for every device list and table (0 = exact).  The
+ * reference sizes each cell for ngridmax rows (egdst_solver.c:198-217) although a solved cell holds about ngridm;
+ * with thousands of draws resident that sparsity costs TLB reach and cache (measured).  All of the
+ * reference's limits (ngridmax in the runaway guard :963, error :662 ...) keep their logical values; a draw that
+ * would write row rows_cap stops with EGDST_E_CAPACITY instead and must be solved again on an exact handle
+ * (egdst_amd.runtime.Solver does that transparently).  Results of the draws that fit are bit-identical. */
+int egdst_create_compact(const egdst_desc *desc, int ndraw, int keep_history, int rows_cap, void *stream,
+                         egdst_handle **out);
 int egdst_destroy(egdst_handle *h);
+/* Physical geometry of the handle: rows per list and row stride of the device tables (egdst_device_tables). */
+int egdst_geometry(egdst_handle *h, int *rows_cap, int *table_stride);
 
 /* Parameter vectors, one row per draw: params[draw*nparam + k] (loadparameters, compile.m:469-475).
  * F8 of SURVEY.md: the batch-of-draws surface is new; ndraw==1 is the reference's setparam+solve. */
 int egdst_set_params(egdst_handle *h, const double *params, int ndraw);
 int egdst_set_params_dev(egdst_handle *h, const double *params_dev, int ndraw);
+int egdst_get_params(egdst_handle *h, double *params /* host, [ndraw*nparam] */);
 
 /* Backward induction for all draws (egdst_solver.c:258-339).  _async only enqueues on the handle's
  * stream; egdst_sync waits and returns the first non-zero per-draw status (or 0). */
@@ -122,6 +135,7 @@ int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, cons
  * is device memory (e.g. a torch tensor) so that the cross-GPU reduce (RCCL) needs no host copy.  Enqueued on
  * the handle's stream. */
 int egdst_objective_dev(egdst_handle *h, double *out_dev);
+int egdst_get_objective(egdst_handle *h, double *out /* host, [2*ndraw] */);
 
 /* Measurement: with profiling on, every kernel launch of a solve is bracketed by HIP events on
  * the handle's stream.  egdst_get_profile returns, for {0: probe/terminal, 1: grid, 2: envelope}, the summed

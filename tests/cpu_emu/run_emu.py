@@ -20,7 +20,7 @@ def run(model, sanitize=True, env_bs=1, parallel_blocks=False, wave=1):
     if not os.path.exists(spec) or open(spec).read() != text:
         open(spec, 'w').write(text)
     lib = runtime.ModelLibrary(build_emu.build(d, sanitize, env_bs, parallel_blocks, wave))
-    s = runtime.Solver(lib, model.descriptor(), ndraw=1, keep_history=True)
+    s = runtime.Solver(lib, model.descriptor(), ndraw=1, keep_history=True, rows_cap=int(os.environ.get('EMU_ROWS_CAP', '0')))
     s.set_params(model.param_vector())
     rc = s.solve(raise_on_error=False)
     sol = s.solution(0)
@@ -38,4 +38,4 @@ if __name__ == '__main__':
                                 bool(int(os.environ.get('EMU_PAR_BLOCKS', '0'))), int(os.environ.get('EMU_WAVE', '1')))
     print(name, 'ok=%s status=%d where=%s rows=%d/%d evals=%d/%d max_rel=%.2e max_dth=%.2e %s' % (
         ok, sol.status, sol.where, sol.total_rows(), ref.total_rows(), sol.nevals, ref.nevals, rep['max_rel'],
-        rep['max_dth'], rep['problems'][:3]))
+        rep['max_dth'], rep['problems'][:3]), 'geometry', s.geometry(), 'capacity_retries', s.capacity_retries)

@@ -16,7 +16,7 @@ def run(model, P, keep_history, sanitize='address', env_bs=1, wave=1):
     os.makedirs(d, exist_ok=True)
     open(os.path.join(d, 'modelspec.h'), 'w').write(text)
     lib = runtime.ModelLibrary(build_emu.build(d, sanitize, env_bs, False, wave))
-    s = runtime.Solver(lib, model.descriptor(), ndraw=len(P), keep_history=keep_history)
+    s = runtime.Solver(lib, model.descriptor(), ndraw=len(P), keep_history=keep_history, rows_cap=int(os.environ.get('EMU_ROWS_CAP', '0')))
     s.set_params(P)
     s.solve(raise_on_error=False)
     st, wh = s.status()
@@ -29,6 +29,7 @@ def run(model, P, keep_history, sanitize='address', env_bs=1, wave=1):
         if keep_history:
             okc, _ = compare(s.solution(i), r, 0.0, 0.0)
         res.append((int(st[i]), tuple(int(x) for x in wh[i]), int(ev[i]), r.nevals, okc))
+    print('geometry', s.geometry(), 'capacity_retries', s.capacity_retries)
     return res
 
 
