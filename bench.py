@@ -56,8 +56,10 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='C2')
-    ap.add_argument('--ndraw', type=int, default=256, help='parameter draws per GPU (weak scaling)')
+    ap.add_argument('--ndraw', type=int, default=4096, help='parameter draws per GPU (weak scaling)')
+    ap.add_argument('--rows-cap', type=int, default=0, help='compact physical row capacity (0 = exact, ngridmax rows)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-single-solve', action='store_true', help='skip the one-draw latency leg (profiling runs)')
     args = ap.parse_args()
 
     import torch
@@ -82,7 +84,7 @@ def main():
     mine = np.ascontiguousarray(all_draws[rank * ndraw:(rank + 1) * ndraw])
 
     stream = torch.cuda.Stream()
-    solver = runtime.Solver(lib, desc, ndraw=ndraw, keep_history=False, stream=stream.cuda_stream)
+    solver = runtime.Solver(lib, desc, ndraw=ndraw, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap)
     params_dev = torch.from_numpy(mine).cuda()          # inputs resident in HBM before the timed region
     obj = torch.zeros(ndraw, 2, dtype=torch.float64, device='cuda')
     torch.cuda.synchronize()
@@ -111,9 +113,12 @@ def main():
     evals_step, _ = solver.evals()
     kms, klaunch, algbytes = solver.profile()       # of the LAST step (events are re-recorded every step)
     # final objective reduce (the only collective of the path, RCCL over xGMI when world > 1)
-    with torch.cuda.stream(stream):
-        solver.objective_dev(obj.data_ptr())
-    stream.synchronize()
+    if solver.rows_cap:
+        obj = torch.from_numpy(solver.objective()).cuda()   # includes the draws redone with exact capacities
+    else:
+        with torch.cuda.stream(stream):
+            solver.objective_dev(obj.data_ptr())
+        stream.synchronize()
     okmask = ~torch.isnan(obj[:, 0])
     red = torch.stack([torch.where(okmask, obj[:, 0], torch.zeros_like(obj[:, 0])).sum(), okmask.sum().double()])
     tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -133,14 +138,26 @@ def main():
         bytes_per_launch = algbytes / max(klaunch[dom], 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # single-solve latency (one draw) for the "full backward-induction wall time" half of the metric
-        s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
-        s1.set_params(mine[:1])
-        s1.solve()
-        t1 = time.perf_counter()
-        for _ in range(3):
+        single_ms = None
+        if not args.no_single_solve:
+            s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
+            s1.set_params(mine[:1])
             s1.solve()
-        single_ms = (time.perf_counter() - t1) / 3 * 1e3
-        s1.close()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                s1.solve()
+            single_ms = (time.perf_counter() - t1) / 3 * 1e3
+            s1.close()
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the figure is
+        # the one measured by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this command and committed
+        # under profiles/ (see profiles/README.md), used only when it was taken on the same configuration
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            if (tj['workload'], tj['ndraw'], tj['rows_cap'], tj['kernel']) == (args.workload, ndraw, args.rows_cap, 'k_' + names[dom]):
+                traffic = tj['fetch_bytes_per_launch'] + tj['write_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'EGM grid-point x shock evals/sec (batched backward induction, all draws, all periods)',
             'value': evals_all / (dt_max / args.steps), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
@@ -149,20 +166,22 @@ def main():
             'config': {'workload': '%s: %s, T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (
                 args.workload, model.label, desc['T'], desc['ngridm'], desc['ny'], lib.info.nd, lib.info.nst,
                 desc['a0'], desc['mmax']), 'ndraw_per_gpu': ndraw, 'ndraw_total': ndraw * world,
+                'rows_cap': args.rows_cap,
                 'parallelism': 'draws sharded over %d rank(s), no data-path collective' % world},
             'evals_per_step': evals_all, 'failed_draws_rank0': int((status != 0).sum()),
-            'single_solve_ms': single_ms,
+            'single_solve_ms': single_ms, 'capacity_retries': solver.capacity_retries,
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
             'kernel_ms_per_step': {n: float(v) for n, v in zip(names, kms)},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + names[dom], 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
                          'launches': int(klaunch[dom])},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, mine)
             out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']
-            out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / single_ms
+            if single_ms:
+                out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / single_ms
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -33,6 +33,7 @@ struct Geom {
 // Device-resident state of a batch (all pointers are device memory).
 struct Batch {
     Geom g;
+    int draw0;           // first draw of the group this launch works on (groups run on their own streams)
     const double *par;   // [ndraw][MS_NPARAM]
     const double *qw;    // [ny] weights
     const double *qz;    // [ny] standard-normal nodes (Acklam of the GL abscissae, egdst_solver.c:164)
@@ -40,6 +41,7 @@ struct Batch {
     double *tM, *tC, *tV;   // * Sp
     double *tD, *tTH;       // * nthrhmax
     int *tlen, *tthlen;     // rows incl. the a0 row (0 = unsolved), thresholds
+    int *thw, *thhw;        // rows / thresholds of the cell that may be non-zero (>= tlen, tthlen)
     // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*Cp + n); n=0 is the probe's point
     double *cM, *cC, *cV, *cR;  // M, C, V, and the M returned to the guess generator
     int *cSt, *cCnt;            // status (0 normal, 1 c1<=0, 2 evf=-inf), evaluations done for the point

@@ -27,6 +27,7 @@
 #define ENV_BS 256
 #endif
 #define EG_WAVE WAVE
+#define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (8 * WAVE)
 #endif
@@ -69,7 +70,7 @@ static __device__ __forceinline__ size_t eg_cand(const Batch &b, int draw, int i
 __global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
 {
     const int combo = blockIdx.y;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
     const int i = blockIdx.x * GRID_BS + threadIdx.x;
     if (b.status[draw]) return;
     ms_env E = eg_env(b, draw);
@@ -341,6 +342,8 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     int ngenerated = 0, ncalls = 0, keep = 0, ntogenerate = b.g.ngridm, np = 0, nev = 0, grid = 0;
     double baseM = 0, baseA = 0, lim1 = 0, lim2 = 0, lim2p = 0, lim3 = 0, lim3p = 0, k3 = 0, last = 0, M = INFINITY;
     double evfa0 = 0.0;
+    int last_cnt = 0;  // evaluations of the most recent expectation
+    int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
     for (;;) {
         // ---- next guess -------------------------------------------------------------------
         if (ncalls + 1 >= b.g.ngridmax) {  // runaway guard (:963-978): the stream simply ends
@@ -348,6 +351,15 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
             break;
         }
         if (ngenerated == 0) {
+            if (M == INFINITY && ncalls > 0) {
+                // Stage 0 asked for mmax and got M=+inf back: the generator asks for mmax again, and the expectation
+                // is a pure function of the guess, so every further call repeats this one until the runaway guard
+                // (:963-978) ends the stream.  Account for those calls instead of executing them.
+                const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still evaluate
+                nev += k * last_cnt;
+                ncalls = b.g.ngridmax;
+                break;
+            }
             ncalls += 1;
             keep = 0;
             if (M == INFINITY)
@@ -398,6 +410,17 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 // the next call either starts the closed-form grid (handled by k_grid) or ends the stream
                 grid = (M < mmax && ngenerated < ntogenerate) ? 1 : 0;
                 break;
+            } else if (full && seq_left > 0 && M < mmax && ngenerated < ntogenerate) {
+                // Right after a resend the next guess often signals c1<=0 again (streams that re-base at every
+                // point exist): take the next few grid guesses one at a time, evaluated cooperatively below,
+                // before paying for a whole batch of speculative evaluations again.
+                GridLims GL;
+                GL.lim1 = lim1, GL.lim2 = lim2, GL.lim3 = lim3, GL.lim3p = lim3p, GL.k3 = k3, GL.ntogenerate = ntogenerate;
+                last = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, ngenerated);
+                ngenerated += 1;
+                ncalls += 1;
+                keep = 1;
+                seq_left -= 1;
             } else if (M < mmax && ngenerated < ntogenerate) {
                 // Grid stage of the sequential stream (:1100-1149), WAVE guesses at a time: lane l evaluates the
                 // guess the generator would emit l calls from now (serial shock loop inside the lane, as k_grid
@@ -484,7 +507,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                     csum += sx_cnt[w];
                     anyinf = anyinf || sx_inf[w] != 0;
                 }
-                if (np + nkept >= b.g.ngridmax - 1) {  // (:662)
+                if (np + nkept > b.g.ngridmax - 1) {  // (:662) the point that makes the count reach ngridmax
                     if (lead) eg_fail(b, draw, it, ist, 13);
                     return;
                 }
@@ -509,6 +532,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 }
                 keep = 1;
                 if (negnext) {  // the next call hit c1<=0 (:583-621): prepare the resend
+                    seq_left = EG_SEQ_AFTER_RESEND;
                     ms_pv nb;
                     nb.it = it + 1;
                     nb.ist = sx_bist;
@@ -537,7 +561,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         double rhs, evf;
         int bist = 0;
         double bshock = 0, bcash = 0;
+        const int nev0 = nev;
         int st = eg_wave_expectation(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash);
+        last_cnt = nev - nev0;
         if (st < 0) {
             if (lead) eg_fail(b, draw, it, ist, -st);
             return;
@@ -550,6 +576,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
             evfa0 = -INFINITY;
             M = bcash;
             if (st == 1) {
+                seq_left = EG_SEQ_AFTER_RESEND;
                 ms_pv nb;
                 nb.it = it + 1;
                 nb.ist = bist;
@@ -589,6 +616,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
             np += 1;  // full == 0: at most one kept point can precede the grid stage
         }
     }
+#ifdef EGDST_EMU
+    if (lead && full && getenv("EGDST_TRACE_FIXUP"))
+        fprintf(stderr, "fixup end it=%d id=%d ncalls=%d ngen=%d np=%d last=%g M=%g nev=%d\n", it, id, ncalls, ngenerated, np, last, M, nev);
+#endif
     if (lead) {
         P->active = 1;
         P->seq = full;
@@ -611,7 +642,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
 __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
 {
     const int combo = blockIdx.x;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
     if (b.status[draw]) return;
     eg_adraw_cycle<1, 0>(b, it, draw, ist, id);
 }
@@ -621,7 +652,7 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
 __global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
 {
     const int combo = blockIdx.x;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
     if (b.status[draw]) return;
     const int lane = threadIdx.x & (WAVE - 1);  // every wave of the workgroup takes the same decisions
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
@@ -655,7 +686,7 @@ __global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
 __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
 {
     const int combo = blockIdx.y;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
     const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
     if (b.status[draw]) return;
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
@@ -1031,7 +1062,7 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
-    const int ist = blockIdx.x % MS_NST, draw = blockIdx.x / MS_NST;
+    const int ist = blockIdx.x % MS_NST, draw = b.draw0 + blockIdx.x / MS_NST;
     const int tid = threadIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
@@ -1049,6 +1080,13 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
     }
+    // Rows of this cell that may hold non-zero leftovers of an earlier period (ping-pong slots) or of an earlier
+    // solve.  The reference reads one row past a table's end when the table has a single row (linter on n=1,
+    // egdst_lib.c:123-206) and finds zeros there, because every period owns a freshly zeroed matrix
+    // (egdst_solver.c:198-217): the rows past the new length are zeroed below to keep exactly that.
+    const int hw_rows = b.thw[tk], hw_th = b.thhw[tk];
+    __syncthreads();
+    if (tid == 0) b.thw[tk] = b.g.Sp, b.thhw[tk] = b.g.nthrhmax;  // until this cell is complete: unknown
     const int ngridmax = b.g.ngridmax, ngridm = b.g.ngridm;
     const double mmax = b.g.mmax;
     const int compact = b.g.Cp < ngridmax;  // physical capacity below the logical one: overflow = EGDST_E_CAPACITY
@@ -1354,13 +1392,22 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
             outm = s_m;
         }
     }
+    for (int i = outn + 1 + tid; i < hw_rows; i += ENV_BS) oM[i] = oC[i] = oV[i] = 0.0;
+    for (int i = outm + tid; i < hw_th; i += ENV_BS) oTH[i] = oD[i] = 0.0;
     // ---- row 0 and lengths (saveoutput :917-952; evf(a0) :730) ------------------------------------
     if (tid == 0) {
+        b.thw[tk] = outn + 1;
+        b.thhw[tk] = outm;
         oM[0] = b.g.a0;
         oC[0] = 0;
         oV[0] = s_evfa0[(int)oD[0]];
         b.tlen[tk] = outn + 1;
         b.tthlen[tk] = outm;
+#ifdef EGDST_EMU
+        if (getenv("EGDST_TRACE_ENV"))
+            fprintf(stderr, "env it=%d draw=%d outn=%d outm=%d V0=%.17g M1=%.17g C1=%.17g V1=%.17g Mn=%.17g Vn=%.17g\n", it, draw, outn, outm, oV[0],
+                    oM[1], oC[1], oV[1], oM[outn], oV[outn]);
+#endif
         if (evals) atomicAdd(&b.evals[draw], evals);
         {   // algorithmic bytes of this cell: its rows written once (M, C, V; A = M - C is derived on export) and,
             // for the EGM periods, the next-period table of the same state index read once

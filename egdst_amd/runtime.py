@@ -31,7 +31,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry']
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -64,6 +64,7 @@ class ModelLibrary:
         L.egdst_create.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.egdst_create_compact.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.POINTER(C.c_void_p)]
+        L.egdst_set_groups.argtypes = [C.c_void_p, C.c_int]
         L.egdst_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_objective.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.egdst_get_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -171,6 +172,10 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+    def set_groups(self, ngroups):
+        """Split the draws into `ngroups` ranges that run on their own streams (egdst_set_groups)."""
+        self.lib.check(self.lib.lib.egdst_set_groups(self.h, int(ngroups)))
 
     def geometry(self):
         """(physical rows per list, row stride of the device tables)"""

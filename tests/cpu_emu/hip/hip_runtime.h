@@ -140,6 +140,9 @@ typedef void *hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, int) { *e = (hipEvent_t)1; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)malloc(n ? n : 1); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void *p) { free(p); return 0; }

@@ -144,3 +144,53 @@ def test_errors_are_reported_not_hidden():
     assert sol.len[sol.nt - 1, 0] > 0 and sol.len[0, 0] == 0       # partial result: terminal period only
     with pytest.raises(runtime.EgdstRuntimeError):
         s.solve(raise_on_error=True)
+
+
+DEGENERATE = (550, 348, 293)   # draws of workloads.c2() on which the reference algorithm itself breaks down
+
+
+def test_degenerate_draws_fail_like_the_oracle_with_pingpong_tables():
+    """Draws whose guess stream re-bases at every point end in a one-row table; the reference then reads one row
+    past the table's end and finds zeros (fresh matrix per period).  With two ping-pong periods the device must
+    zero the rows past the new length to see the same: status, failing period and message equal the oracle's."""
+    m, gen = workloads.c2()
+    P = gen(1024)[list(DEGENERATE) + [0]]
+    orc = Oracle(m)
+    refs = [orc.solve(p) for p in P]
+    for keep in (True, False):
+        s = gpu_solve(m, P, keep_history=keep)
+        st, wh = s.status()
+        ev = s.evals()[1]
+        for i, r in enumerate(refs):
+            assert (st[i] == 0) == (r.rc == 0), (keep, i, st[i], r.err)
+            if r.rc:
+                assert s.lib.lib.egdst_strerror(int(st[i])).decode().strip() == r.err.strip(), (keep, i)
+            else:
+                assert ev[i] == r.nevals
+
+
+def test_draw_groups_and_compact_capacity_do_not_change_results():
+    """Grouping draws on concurrent streams and the compact physical row capacity (with the exact redo of the
+    draws that overflow it) are layout and scheduling choices only: per-draw status, evaluation counts,
+    objective values and exported cells are bit-identical to the plain handle's."""
+    m, gen = workloads.c2(ngridm=300, T=30)
+    P = gen(24)
+    lib = build.build_model(m)
+    base = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=True)
+    base.set_params(P)
+    base.solve(raise_on_error=False)
+    st0, ev0, ob0 = base.status()[0], base.evals()[1], base.objective()
+    rows = max(int(base.solution(i).len.max()) for i in range(len(P)))
+    for groups, cap in ((5, 0), (1, rows + 8), (3, rows - 4)):   # the last capacity forces redo of some draws
+        s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=True, rows_cap=cap)
+        s.set_groups(groups)
+        s.set_params(P)
+        s.solve(raise_on_error=False)
+        assert np.array_equal(s.status()[0], st0) and np.array_equal(s.evals()[1], ev0)
+        assert np.array_equal(s.objective(), ob0, equal_nan=True)
+        if cap and cap < rows:
+            assert s.capacity_retries > 0
+        for i in (0, 7, 23):
+            a, b = s.solution(i), base.solution(i)
+            assert np.array_equal(a.len, b.len) and np.array_equal(a.M, b.M) and np.array_equal(a.V, b.V, equal_nan=True)
+        s.close()

@@ -40,3 +40,28 @@ def test_batched_draws_and_pingpong_tables():
         st, where, ev, ev_ref, same = eval(ln.split(' ', 2)[2])
         assert st == 0 and ev == ev_ref and same in (True, None), ln
     assert 'ERROR: AddressSanitizer' not in r.stderr
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+def test_compact_capacity_overflow_is_redone_exactly():
+    """rows_cap below what the model needs: the device reports EGDST_E_CAPACITY without touching memory past the
+    compact arrays (ASan), the host solves the draw again on an exact handle, the result equals the oracle's."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EMU_ROWS_CAP='64')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py'), 'retirement2', 'T=8, ngridm=60'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout and 'capacity_retries 1' in r.stdout, r.stdout
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
+    """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=12): with ping-pong
+    tables the failure must be the oracle's (error 15 at it=11), not a success built on stale rows."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_draws.py'), '550'],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('keep_history')]
+    assert len(lines) == 2, r.stdout
+    for ln in lines:
+        st, where, ev, ref_rc = eval(ln.split(' ', 3)[3])
+        assert st == 15 and where == (11, 0) and ref_rc != 0, ln
