@@ -29,6 +29,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import egdst_amd  # noqa: E402,F401  (before torch starts the HIP runtime: sets GPU_MAX_HW_QUEUES, see egdst_amd/__init__.py)
 
 
 def cpu_baseline(model, draws, budget_s=12.0):

@@ -41,6 +41,7 @@ struct Batch {
     double *tM, *tC, *tV;   // * Sp
     double *tD, *tTH;       // * nthrhmax
     int *tlen, *tthlen;     // rows incl. the a0 row (0 = unsolved), thresholds
+    int *defer;             // [ndraw*MS_NST] cell left for the large-LDS pass of k_envelope
     int *thw, *thhw;        // rows / thresholds of the cell that may be non-zero (>= tlen, tthlen)
     // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*Cp + n); n=0 is the probe's point
     double *cM, *cC, *cV, *cR;  // M, C, V, and the M returned to the guess generator

@@ -855,12 +855,15 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
 // stream goes through a bitonic network instead (padded to a power of two); the per-function position lists
 // are then rebuilt from the sorted stream with one block scan per function.
 // Returns the position lists (rank[fstart[f]+k] = sorted position of the k-th point of f).
+// LDS regions (lcap entries each): R1, R2, R3 doubles; Lf, Lp ints.  Keys are staged in R1 (M) and R2 (V); the
+// sorted stream ends up as M in R2, V in R3 and C in R1 (a key region is recycled as soon as every thread has
+// read it), so a point costs 36 B of LDS including its class word.
 static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const double *im, const double *ic,
                                                         const double *iv, const int *ifn, const eg_ldsi *fstart,
-                                                        const eg_ldsi *dims, eg_ldsd *Km, eg_ldsd *Kv, eg_ldsd *Lm,
-                                                        eg_ldsd *Lc, eg_ldsd *Lv, eg_ldsi *Lf, eg_ldsi *Lp, int lcap,
-                                                        int *sh, int *oob)
+                                                        const eg_ldsi *dims, eg_ldsd *R1, eg_ldsd *R2, eg_ldsd *R3,
+                                                        eg_ldsi *Lf, eg_ldsi *Lp, int lcap, int *sh, int *oob)
 {
+    eg_ldsd *Km = R1, *Kv = R2, *Lm = R2, *Lv = R3, *Lc = R1;
     const int tid = threadIdx.x;
     for (int i = tid; i < npts; i += ENV_BS) {
         Km[i] = im[i];
@@ -904,14 +907,18 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
             }
             if (r < 0 || r >= npts) {
                 *oob = 1;
-                continue;
-            }
+                r = -1;
+            } else
+                Lf[r] = f;
             Lp[i] = r;
-            Lm[r] = m;
-            Lv[r] = v;
-            Lc[r] = ic[i];
-            Lf[r] = f;
         }
+        __syncthreads();  // every rank is known
+        if (*oob) return Lp;
+        for (int i = tid; i < npts; i += ENV_BS) Lv[Lp[i]] = Kv[i];  // R2 -> R3
+        __syncthreads();
+        for (int i = tid; i < npts; i += ENV_BS) Lm[Lp[i]] = Km[i];  // R1 -> R2 (V keys are consumed)
+        __syncthreads();
+        for (int i = tid; i < npts; i += ENV_BS) Lc[Lp[i]] = ic[i];  // -> R1 (M keys are consumed)
         __syncthreads();
         if (!bad) return Lp;
     } else {
@@ -944,15 +951,15 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
                 }
                 __syncthreads();
             }
-        for (int r = tid; r < npts; r += ENV_BS) {
-            Lm[r] = Km[r];
-            Lv[r] = Kv[r];
-            Lc[r] = ic[Lp[r]];
+        for (int r = tid; r < npts; r += ENV_BS) {  // same index in every region: no cross-thread hazard
+            Lv[r] = Kv[r];      // R2 -> R3
+            Lm[r] = Km[r];      // R1 -> R2
+            Lc[r] = ic[Lp[r]];  // -> R1
         }
         __syncthreads();
     }
-    // position lists from the sorted stream (the key buffer is free now)
-    eg_ldsi *posl = (eg_ldsi *)Km;
+    // position lists from the sorted stream (Lp held input indices or ranks; both are consumed)
+    eg_ldsi *posl = Lp;
     for (int g = 0; g < nf; g++) {
         if (dims[g] <= 0) continue;
         int carry = 0;
@@ -980,7 +987,7 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
         return;                                          \
     } while (0)
 #ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
-#define EG_DYN_LDS(name) static double name[28672]
+#define EG_DYN_LDS(name) static double name[20480]
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
 #endif
@@ -1052,8 +1059,11 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     }
 }
 
-// lcap: sorted points that fit the dynamic LDS (48 B each: staged keys, sorted M/C/V, function id, position list)
-__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal, int lcap)
+// lcap: sorted points that fit the dynamic LDS (36 B each: sorted M/C/V, function id, position list, class word).
+// pass 0: launched with a small lcap so that two workgroups share a CU; a cell whose stream does not fit is left
+//         untouched and flagged in b.defer;  pass 1: launched with the large lcap, works on the flagged cells only
+//         (streams beyond that sort and walk in global memory);  pass 2: every cell, one launch (no deferral).
+__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
 {
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_BS];
@@ -1066,6 +1076,12 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     const int tid = threadIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    const size_t cell = (size_t)draw * MS_NST + ist;
+    if (pass == 1) {
+        if (!b.defer[cell]) return;  // done in pass 0
+        __syncthreads();
+        if (tid == 0) b.defer[cell] = 0;
+    }
     if (b.status[draw]) {
         if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
@@ -1103,8 +1119,8 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
     double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
-    eg_ldsd *Km = (eg_ldsd *)dynlds, *Kv = Km + lcap, *Lm = Kv + lcap, *Lc = Lm + lcap, *Lv = Lc + lcap;
-    eg_ldsi *Lf = (eg_ldsi *)(Lv + lcap), *Lr = Lf + lcap, *Lq = Lr + lcap;
+    eg_ldsd *R1 = (eg_ldsd *)dynlds, *R2 = R1 + lcap, *R3 = R2 + lcap;
+    eg_ldsi *Lf = (eg_ldsi *)(R3 + lcap), *Lr = Lf + lcap, *Lq = Lr + lcap;
     eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
 
     WalkJob job;
@@ -1349,15 +1365,24 @@ __global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int termin
         }
         // ---- common: sort the stream (comp1 order) and walk it ----------------------------------------
         if (job.npts <= lcap) {
-            const eg_ldsi *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, Km, Kv, Lm, Lc, Lv, Lf, Lr,
-                                               lcap, sh, &s_oob);
+            const eg_ldsi *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
+                                               sh, &s_oob);
             STAMP(3);  // LDS sort
             if (s_oob) ENV_FAIL(2704);
             {
                 int we = 0, wn = 0, wm = 0;
-                run_walk<true>(&E, job, Lm, Lc, Lv, Lf, posl, Lq, &we, &wn, &wm);
+                run_walk<true>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm);  // sorted M, C, V
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
+        } else if (pass == 0) {
+            // does not fit the small LDS of this pass: leave the cell exactly as it was for pass 1
+            if (tid == 0) {
+                b.defer[cell] = 1;
+                b.dbg[16 * draw + 15] += 1;  // diagnostic: deferrals of this draw
+                b.thw[tk] = hw_rows;
+                b.thhw[tk] = hw_th;
+            }
+            return;
         } else {
             blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg);
             if (s_oob) ENV_FAIL(2714);

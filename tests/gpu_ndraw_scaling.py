@@ -18,4 +18,5 @@ for nd in [int(a) for a in sys.argv[2:]]:
     kms, kl, ab = s.profile()
     print('rows_cap', cap, 'geometry', s.geometry(), 'retries', s.capacity_retries, 'ndraw', nd, '%.1f ms' % (dt * 1e3), '%.2f G evals/s' % (ev / dt / 1e9), 'failed', int((st != 0).sum()),
           'probe/grid/env', np.round(kms, 1).tolist(), flush=True)
+    print('   deferrals per draw (first 8):', [int(s.debug(i)[15]) for i in range(min(nd, 8))], 'mean', float(np.mean([s.debug(i)[15] for i in range(min(nd, 64))])))
     s.close()
