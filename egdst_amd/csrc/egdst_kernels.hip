@@ -29,7 +29,7 @@
 #define EG_WAVE WAVE
 #define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
-#define FIX_BS (8 * WAVE)
+#define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
 #endif
 
 #include "egdst_device.h"
