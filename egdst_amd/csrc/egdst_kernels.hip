@@ -991,7 +991,8 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
 #endif
-#define ENV_SMALLF 256  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
+#define ENV_SMALLF 1024  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
+                         // (C5 at full size: 292 pieces in one list; the reference allows 10000, :832)
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
 
 struct WalkJob {  // what one envelope walk needs besides the sorted stream
