@@ -437,6 +437,312 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
     return true;
 }
 
+// ---- wave-cooperative generic step ----------------------------------------------------------------------
+// env_step()/env_crossing() executed by ALL lanes of the walking wave with uniform control flow: the scalar state of
+// the walk (oi, oj, ci, pm, lastg, err ...) lives in every lane's registers and is updated identically; the shared
+// arrays (cur, mark, stack, the output rows) are written by lane 0 only; and every loop over the functions
+// ("is a function above this point", "which function is highest", the third-function test at a crossing) gives one
+// function to each lane and combines the lanes with the reference's own tie rules (strictly-greater wins, ties go
+// to the smaller index; NaN candidates never win, as in the reference's comparisons).  Same arithmetic per function
+// as the sequential code, so the result is bit-identical -- the CPU harness checks that.
+#ifdef EGDST_EMU
+#define EG_WSYNC() ((void)__ballot(1))   // the harness runs lanes as threads: order lane 0's stores before the readers
+#else
+#define EG_WSYNC() __builtin_amdgcn_wave_barrier()  // same wave, in-order LDS: only the compiler must not reorder
+#endif
+
+// (value, index) with the larger value, ties to the smaller index; idx < 0 = absent
+static __device__ __forceinline__ void env_wave_argmax(double *v, int *idx)
+{
+    for (int o = EG_WAVE / 2; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(*v, o);
+        const int oi = __shfl_xor(*idx, o);
+        if (oi >= 0 && (*idx < 0 || ov > *v || (ov == *v && oi < *idx))) *v = ov, *idx = oi;
+    }
+}
+static __device__ __forceinline__ int env_wave_min(int x)
+{
+    for (int o = EG_WAVE / 2; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
+    return x;
+}
+
+// Over the functions j with dims[j] > 0, j != ex1, j != ex2 (and, with marks, mark[j] != 1):
+//   first != 0: the smallest j with thr < value_j(x);   first == 0: the j of the largest value_j(x) > thr,
+//   smallest index among equals.  Returns j (or -1) and its value in *val.
+template <bool L>
+static __device__ __forceinline__ int env_wave_pick(EnvCtxT<L> &e, double x, double thr, int ex1, int ex2, int marks, int first,
+                                                    double *val)
+{
+    const int lane = threadIdx.x & (EG_WAVE - 1);
+    double bv = 0;
+    int bj = -1;
+    for (int j = lane; j < e.nf; j += EG_WAVE) {
+        if (marks ? (e.mark[j] == 1) : (e.dims[j] <= 0 || j == ex1 || j == ex2)) continue;
+        if (first && bj >= 0) break;
+        const double t = env_fn(e, j, x);
+        if (thr < t && (bj < 0 || t > bv)) bv = t, bj = j;  // ascending j: an equal value keeps the earlier index
+    }
+    if (first) {
+        const int j0 = env_wave_min(bj < 0 ? 0x7fffffff : bj);
+        if (j0 == 0x7fffffff) return -1;
+        *val = __shfl(bv, j0 & (EG_WAVE - 1));
+        return j0;
+    }
+    env_wave_argmax(&bv, &bj);
+    if (bj >= 0) *val = bv;
+    return bj;
+}
+
+template <bool L> static __device__ __forceinline__ void env_crossing_wave(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
+{
+    const int lane = threadIdx.x & (EG_WAVE - 1);
+    const double a0 = e.E->a0;
+    int sp = 1;
+    if (lane == 0) e.stack[0] = pri0, e.stack[1] = nwi0;
+    while (sp > 0 && !e.err) {
+        EG_WSYNC();
+        sp--;
+        const int pri = e.stack[2 * sp], nwi = e.stack[2 * sp + 1];
+        EG_WSYNC();
+        if (lane == 0) e.mark[pri] = 1, e.mark[nwi] = 1;
+        const int cp = e.cur[pri], cn = e.cur[nwi];
+        double x = 0, top = 0;
+        if ((cp == -1) != (cn == -1)) {  // exactly one of the two is still in its analytic region (:1648-1688)
+            const int ana = (cp == -1) ? pri : nwi, lin = (cp == -1) ? nwi : pri, kl = (cp == -1) ? cn : cp;
+            if (env_evf(e, ana) == -INFINITY)
+                x = e.m[env_at(e, ana, 0)];
+            else {
+                double br0 = e.m[env_at(e, lin, kl)];
+                double br1 = MS_MIN(e.m[env_at(e, ana, 0)], e.m[env_at(e, lin, kl + 1)]);
+                env_bisect(e, &br0, &br1, lin, kl, ana);
+                if (e.err) return;
+                x = br0;
+            }
+            top = env_seg(e, lin, kl, x, 0);
+        } else if (cp == -1 && cn == -1) {
+            e.err = 21;
+            return;
+        } else {
+            const int ip0 = env_at(e, pri, cp), ip1 = env_at(e, pri, cp + 1);
+            const int in0 = env_at(e, nwi, cn), in1 = env_at(e, nwi, cn + 1);
+            const double p0m = e.m[ip0], p1m = e.m[ip1], p0v = e.v[ip0], p1v = e.v[ip1];
+            const double n0m = e.m[in0], n1m = e.m[in1], n0v = e.v[in0], n1v = e.v[in1];
+            const double icn = (n0v * n1m - n1v * n0m) / (n1m - n0m);  // intercepts
+            const double icp = (p0v * p1m - p1v * p0m) / (p1m - p0m);
+            if (p1m == p0m) {  // previous max is vertical
+                x = p0m;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else if (n1m == n0m) {  // entering function is vertical
+                x = n0m;
+                top = (x * (p1v - p0v) / (p1m - p0m)) + icp;
+            } else if (((n1v - n0v) / (n1m - n0m)) == ((p1v - p0v) / (p1m - p0m))) {  // identical slopes
+                x = (p0m + p1m + n0m + n1m) / 4;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else {
+                x = (icp - icn) / (((n1v - n0v) / (n1m - n0m)) - ((p1v - p0v) / (p1m - p0m)));
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            }
+        }
+        EG_WSYNC();  // the marks of pri and nwi are set
+        const int best = env_wave_pick(e, x, top, -1, -1, 1, mode == 0, &top);
+        if (best != -1) {  // a third function is higher at the crossing: split (:1827-1845)
+            if (2 * (sp + 2) > e.stackcap) {
+                e.err = 2703;
+                return;
+            }
+            if (mode != 0) {
+                if (lane == 0) e.stack[2 * sp] = best, e.stack[2 * sp + 1] = nwi;
+                sp++;
+            }
+            if (lane == 0) e.stack[2 * sp] = pri, e.stack[2 * sp + 1] = best;
+            sp++;
+            continue;
+        }
+        const double pol0 = env_policy(e, pri, x), pol1 = env_policy(e, nwi, x);
+        double gx = x;  // grid value of the row written last (kept for the duplicate test)
+        if (lane == 0) {
+            e.og[e.oi] = x;
+            e.ov[e.oi] = top;
+            e.oc[e.oi] = (pol0 + pol1) / 2;
+            e.oth[e.oj] = x;
+            e.oix[e.oj] = nwi;
+        }
+        e.pm = nwi;
+        e.oi += 1;
+        e.oj += 1;
+        if (e.oi >= e.ocap) {
+            e.err = e.e13;
+            return;
+        }
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return;
+        }
+        if (env_evf(e, nwi) == -INFINITY && e.cur[nwi] == -1) {  // :1892-1900
+            gx = x - EG_TOL;
+            if (lane == 0) {
+                e.oc[e.oi - 1] = pol0;
+                e.og[e.oi - 1] = gx;
+            }
+        } else if (EG_DPD > 0) {  // double point at the kink, :1902-1913
+            gx = x + EG_DPD;
+            if (lane == 0) {
+                e.oc[e.oi - 1] = pol0;
+                e.og[e.oi] = gx;
+                e.ov[e.oi] = top;
+                e.oc[e.oi] = pol1;
+            }
+            e.oi += 1;
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
+                return;
+            }
+        }
+        e.lastg = gx;
+    }
+}
+
+template <bool L> static __device__ __forceinline__ void env_push_wave(EnvCtxT<L> &e, double g, double v, double c, int lane)
+{
+    if (lane == 0) {
+        e.og[e.oi] = g;
+        e.ov[e.oi] = v;
+        e.oc[e.oi] = c;
+    }
+    e.oi++;
+    e.lastg = g;
+}
+
+template <bool L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L> &e, int i)
+{
+    const int lane = threadIdx.x & (EG_WAVE - 1);
+    const double a0 = e.E->a0, bound = e.bound;
+    EG_WSYNC();  // cursors written by the previous step / the rebuild are in place
+    const int f = e.f[i];
+    const double x = e.m[i];
+    if (f < 0 || f >= e.nf || e.dims[f] <= 0) {  // sorted stream inconsistent with the per-function lists
+        if (e.dbg && atomicCAS(&e.dbg[0], 0, 2708) == 0)
+            e.dbg[1] = f, e.dbg[2] = i, e.dbg[3] = e.npts, e.dbg[4] = e.nf, e.dbg[5] = e.sec_id, e.dbg[6] = e.ist;
+        e.err = 2708;
+        return false;
+    }
+    const int curf = e.cur[f];
+    if (e.oi > 0 && e.lastg == x) {  // duplicate grid point (:1290-1298)
+        EG_WSYNC();
+        if (lane == 0) e.cur[f] = curf + 1;
+        return true;
+    }
+    const int self = env_at(e, f, curf + 1);
+    double fv = e.v[self];
+    if (e.oj == 0) {  // first point of the common grid (:1303-1347)
+        // the highest function at x, own value included, smallest index among equals
+        double t = fv;
+        int cj = (lane == (f & (EG_WAVE - 1))) ? f : -1;
+        if (t != t) cj = -1;  // (a NaN own value never loses in the reference: handled below)
+        {
+            double bv = t;
+            int bj = cj;
+            for (int j = lane; j < e.nf; j += EG_WAVE) {
+                if (e.dims[j] <= 0 || j == f) continue;
+                const double tj = env_fn(e, j, x);
+                if (tj != tj) continue;
+                if (bj < 0 || tj > bv || (tj == bv && j < bj)) bv = tj, bj = j;
+            }
+            env_wave_argmax(&bv, &bj);
+            if (fv != fv)
+                e.ci = f;  // every comparison with NaN is false: nothing replaces the own point
+            else
+                t = bv, e.ci = bj;
+        }
+        if (lane == 0) {
+            e.oth[e.oj] = a0;
+            e.oix[e.oj] = e.ci;
+        }
+        e.pm = e.ci;
+        e.oj++;
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return false;
+        }
+        if (e.ci == f) {
+            env_push_wave(e, x, t, e.c[self], lane);
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
+                return false;
+            }
+        }
+    } else {
+        int xa = -1, xb = -1, xmode = 0, post = 0;  // post: 0 nothing, 1 last row of ci, 2 push own point, 3 last row of cj
+        int cj = -1;
+        if (e.pm == f) {  // point of the current max function
+            double t = 0;
+            const int j = env_wave_pick(e, x, fv, f, -1, 0, x != bound, &t);
+            if (j < 0) {
+                env_push_wave(e, x, fv, e.c[self], lane);
+                if (e.oi == e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (x != bound) {
+                xa = f, xb = j, xmode = 0, post = 0;
+            } else {
+                fv = t;
+                e.ci = j;
+                xa = f, xb = e.ci, xmode = 1, post = 1;
+            }
+        } else {  // point of another function
+            e.ci = e.pm;
+            double t = env_fn(e, e.ci, x);
+            if (t < fv) {
+                double tv = 0;
+                cj = env_wave_pick(e, x, fv, f, e.ci, 0, 0, &tv);
+                if (cj == -1)
+                    xa = e.ci, xb = f, xmode = 1, post = 2;
+                else {
+                    fv = tv;
+                    xa = e.ci, xb = cj, xmode = 1, post = (x == bound) ? 3 : 0;
+                }
+            } else if (x == bound) {
+                double vv = env_fn(e, e.ci, x), pp = env_policy(e, e.ci, x);
+                env_push_wave(e, x, vv, pp, lane);
+            }
+        }
+        if (xa >= 0) {
+            for (int l = lane; l < e.nf; l += EG_WAVE) e.mark[l] = (e.dims[l] > 0 ? 0 : 1);
+            env_crossing_wave(e, xa, xb, xmode);
+            if (e.err) return false;
+            if (post == 1) {
+                e.lastg = x;
+                const double vv = env_fn(e, e.ci, x);
+                // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
+                const double pp = (e.cur[e.ci] >= 0) ? env_seg(e, e.ci, e.cur[e.ci], x, 1) : x - a0;
+                if (lane == 0) {
+                    e.og[e.oi] = x;
+                    e.ov[e.oi] = vv;
+                    e.oc[e.oi] = pp;
+                }
+                e.oi++;
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (post == 2) {
+                env_push_wave(e, x, fv, e.c[self], lane);
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (post == 3) {
+                double vv = env_fn(e, cj, x), pp = env_policy(e, cj, x);
+                env_push_wave(e, x, vv, pp, lane);
+            }
+        }
+    }
+    EG_WSYNC();  // every lane has read the cursors it needs
+    if (lane == 0) e.cur[f] = MS_MIN(curf + 1, e.dims[f] - 2);
+    return true;
+}
+
 #ifdef EGDST_SEQ_WALK
 // Plain sequential walk (diagnostic build only).
 template <bool L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e, int npts)
@@ -541,21 +847,6 @@ static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typ
 }
 
 // lane 0 takes one generic step; the few scalars the other lanes need are broadcast afterwards
-template <bool L> static __device__ __forceinline__ bool env_step_lane0(EnvCtxT<L> &e, int i, int lane, double *lastg, int *pm)
-{
-    int ok = 1;
-    if (lane == 0) {
-        e.lastg = *lastg;  // rows committed by the batches since the last generic step
-        ok = env_step(e, i) ? 1 : 0;
-    }
-    e.oi = __shfl(e.oi, 0);
-    e.oj = __shfl(e.oj, 0);
-    e.err = __shfl(e.err, 0);
-    *lastg = __shfl(e.lastg, 0);
-    *pm = __shfl(e.pm, 0);
-    return __shfl(ok, 0) != 0;
-}
-
 template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
@@ -602,8 +893,8 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
             const bool valid = p < npts && e.m[p] < e.bound;
             const unsigned long long vmask = __ballot(valid);
             if (!(vmask & 1ull)) {  // position i is at (or beyond) the bound: sequential tail with rebuilt cursors
-                if (lane == 0)
-                    for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+                for (int j = lane; j < e.nf; j += EG_WAVE) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+                (void)__ballot(1);  // wave-wide: every cursor is written before lane 0 steps
                 phase = 2;
                 continue;
             }
@@ -659,14 +950,18 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
             }
             i += stop;
             step_now = stop < nvalid;
-            if (step_now) {  // irregular position: rebuild the per-function cursors for the generic step
-                if (lane == 0)
-                    for (int j = 0; j < e.nf; j++) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+            if (step_now) {  // irregular position: rebuild the per-function cursors for the generic step, a lane each
+                for (int j = lane; j < e.nf; j += EG_WAVE) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
+                (void)__ballot(1);  // wave-wide: every cursor is written before lane 0 steps
             }
             WSTAMP(w_batch, w_nbatch);
         }
         if (step_now) {
-            if (!env_step_lane0(e, i, lane, &lastg, &pm)) return;
+            e.lastg = lastg;  // rows committed by the batches since the last generic step
+            const bool ok_ = env_step_wave(e, i);
+            lastg = e.lastg;
+            pm = e.pm;
+            if (!ok_) return;
             i++;
             if (phase == 0 && e.oj > 0) phase = 1;
             WSTAMP(w_step, w_nstep);

@@ -5,8 +5,8 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 m, gen = workloads.c2()
 lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps', extra_flags=['-DEGDST_STAMPS'])
-P = gen(4)
-for draw in (0, 1):
+P = gen(64)
+for draw in [int(a) for a in sys.argv[1:]] or (0, 1):
     s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=False)
     s.set_params(P[draw:draw+1]); s.solve()
     s.solve()
