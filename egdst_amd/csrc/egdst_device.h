@@ -133,9 +133,17 @@ MS_FN double eg_shock_uniform(double u, double mu, double sigma)
 #endif
 }
 
+#ifdef EGDST_EMU
+#define EG_LDS_AS
+#else
+#define EG_LDS_AS __attribute__((address_space(3)))
+#endif
+typedef EG_LDS_AS double eg_ldsd;
+typedef EG_LDS_AS int eg_ldsi;
+
 // ---- bracket search + interpolation (egdst_lib.c:123-206) -----------------------------------
 // kind 0: bracket for interpolation/extrapolation; kind 1: last threshold <= x.
-static __device__ __forceinline__ int eg_bracket(double x, const double *__restrict__ g, int n, int kind)
+template <class P> static __device__ __forceinline__ int eg_bracket(double x, P g, int n, int kind)
 {
     if (x < g[1]) return 0;
     if (kind == 0 && x >= g[n - 2]) return n - 2;
@@ -158,10 +166,13 @@ static __device__ __forceinline__ double eg_lerp(double x, double g0, double g1,
 }
 
 // One next-period table (state ist1 of period it+1), row 0 = (a0, 0, evf(a0)).
-struct Tab {
-    const double *M, *C, *V, *TH, *D;
+template <class PD> struct TabT {
+    PD M, C, V;
+    const double *TH, *D;
     int len, thlen;  // rows incl. the a0 row; thresholds
 };
+typedef TabT<const double *> Tab;    // in global memory
+typedef TabT<const eg_ldsd *> TabL;  // M, C, V staged in LDS (k_fixup's sequential stretches)
 
 static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw, int ist)
 {
@@ -178,11 +189,11 @@ static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw,
 }
 
 // Next-period value at nxt->cash (valuefunc, egdst_solver.c:755-772 with linter_extrap, egdst_lib.c:179-206).
-static __device__ __forceinline__ double eg_next_value(const ms_env *E, const Tab &t, const ms_pv *nxt)
+template <class TT> static __device__ __forceinline__ double eg_next_value(const ms_env *E, const TT &t, const ms_pv *nxt)
 {
     const double evf1 = t.V[0], a0 = E->a0, x = nxt->cash;
     if (x < t.M[1] && evf1 > -INFINITY) return ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
-    const double *g = t.M + 1, *f = t.V + 1;
+    const auto g = t.M + 1, f = t.V + 1;
     const int n = t.len - 1;
     int i = eg_bracket(x, g, n, 0);
     double f0 = f[i], f1 = f[i + 1];
@@ -198,7 +209,8 @@ static __device__ __forceinline__ double eg_next_value(const ms_env *E, const Ta
 
 // One (next state, shock node) term of the expectation: the body at egdst_solver.c:548-570.
 // Returns c1; on c1>0 fills the two weighted terms.  nxt->ist/shock must be set; fills nxt->cash, nxt->id.
-static __device__ __forceinline__ double eg_term(const ms_env *E, const Tab &t, const ms_pv *cur, ms_pv *nxt,
+template <class TT>
+static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, const ms_pv *cur, ms_pv *nxt,
                                                  double pr1, int keep, double *t_rhs, double *t_evf)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);

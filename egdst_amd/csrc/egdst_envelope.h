@@ -16,13 +16,7 @@
 // parameter L), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
 // avoided on purpose -- selecting between LDS- and global-derived generic pointers made hipcc's backend fail
 // ("Illegal instruction detected ... src_shared_base") on one model, and typed LDS accesses are ds_* ops anyway.
-#ifdef EGDST_EMU
-#define EG_LDS_AS
-#else
-#define EG_LDS_AS __attribute__((address_space(3)))
-#endif
-typedef EG_LDS_AS double eg_ldsd;
-typedef EG_LDS_AS int eg_ldsi;
+// (EG_LDS_AS, eg_ldsd, eg_ldsi: typed LDS pointers, defined in egdst_device.h)
 template <bool L> struct EgMem {
     typedef double D;
     typedef int I;

@@ -27,6 +27,7 @@
 #define ENV_BS 256
 #endif
 #define EG_WAVE WAVE
+#define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
 #define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
@@ -231,9 +232,11 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
 // current next-state; the weighted terms are then accumulated in (ist1 asc, iy asc) order by every
 // lane redundantly, so that sums and early exits equal the serial loop (egdst_solver.c:494-574).
 // Returns 0 normal, 1 c1<=0, 2 evf=-inf, <0 hard error (-code).  brk_* describe the break point.
+// TT: table type; `lt` (TabL only): the next-period table of state 0 staged in LDS by the caller (MS_NST == 1).
+template <class TT>
 static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
                                           double savings, int keep, double *rhs_o, double *evf_o, int *nev,
-                                          int *brk_ist, double *brk_shock, double *brk_cash)
+                                          int *brk_ist, double *brk_shock, double *brk_cash, const TT *lt)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int ny = b.g.ny;
@@ -255,7 +258,14 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
             if (pr1pre == 0.0) continue;
         }
         const int niy = (ms_sigma(E, cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
-        const Tab t = eg_tab(b, slot1, draw, ist1);
+        TT t;
+        if (lt)
+            t = *lt;
+        else {
+            const Tab tg = eg_tab(b, slot1, draw, ist1);
+            t.M = (decltype(t.M))tg.M, t.C = (decltype(t.C))tg.C, t.V = (decltype(t.V))tg.V;  // (TT == Tab here)
+            t.TH = tg.TH, t.D = tg.D, t.len = tg.len, t.thlen = tg.thlen;
+        }
         if (t.len < 2) return -10;
         if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
         for (int base = 0; base < niy && status == 0; base += WAVE) {
@@ -342,6 +352,30 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     int ngenerated = 0, ncalls = 0, keep = 0, ntogenerate = b.g.ngridm, np = 0, nev = 0, grid = 0;
     double baseM = 0, baseA = 0, lim1 = 0, lim2 = 0, lim2p = 0, lim3 = 0, lim3p = 0, k3 = 0, last = 0, M = INFINITY;
     double evfa0 = 0.0;
+    // k_fixup, one next state: the next-period table goes to LDS once, so that the two searches of every cooperative
+    // expectation of a re-basing stream are LDS reads instead of dependent L2 loads (the row past the end is part of
+    // the table: the reference reads it for one-row tables)
+    bool staged = false;
+    TabL ltab;
+    ltab.M = ltab.C = ltab.V = nullptr, ltab.TH = ltab.D = nullptr, ltab.len = ltab.thlen = 0;
+    if (full && MS_NST == 1) {
+        __shared__ double fx_tab[3 * EG_FIX_LROWS];
+        const Tab tg = eg_tab(b, slot1, draw, 0);
+        const int nrow = min(tg.len + 1, b.g.Sp);
+        staged = tg.len >= 2 && nrow <= EG_FIX_LROWS;
+        if (staged) {
+            for (int i = threadIdx.x; i < nrow; i += NW * WAVE) {
+                fx_tab[i] = tg.M[i];
+                fx_tab[EG_FIX_LROWS + i] = tg.C[i];
+                fx_tab[2 * EG_FIX_LROWS + i] = tg.V[i];
+            }
+            ltab.M = (const eg_ldsd *)fx_tab;
+            ltab.C = ltab.M + EG_FIX_LROWS;
+            ltab.V = ltab.M + 2 * EG_FIX_LROWS;
+            ltab.TH = tg.TH, ltab.D = tg.D, ltab.len = tg.len, ltab.thlen = tg.thlen;
+        }
+        __syncthreads();
+    }
     int last_cnt = 0;  // evaluations of the most recent expectation
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
     for (;;) {
@@ -562,7 +596,12 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         int bist = 0;
         double bshock = 0, bcash = 0;
         const int nev0 = nev;
-        int st = eg_wave_expectation(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash);
+        int st;
+        if (full && staged)
+            st = eg_wave_expectation<TabL>(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash, &ltab);
+        else
+            st = eg_wave_expectation<Tab>(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash,
+                                          (const Tab *)nullptr);
         last_cnt = nev - nev0;
         if (st < 0) {
             if (lead) eg_fail(b, draw, it, ist, -st);
@@ -891,8 +930,21 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
                         r += i - s0;
                         continue;
                     }
-                    int lo = 0, hi = dg;
-                    while (lo < hi) {
+                    // the list is in comp1 order: most lists lie entirely on one side of the point (pieces of a
+                    // folded choice list overlap only near the kinks), which two or three key reads settle
+                    if (!pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) continue;  // none of g precedes the point
+                    int lo = 1, hi = dg;
+                    if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i)) {
+                        r += dg;  // all of g precede it
+                        continue;
+                    }
+                    hi = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
+                    if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i)) {
+                        r += dg - 1;
+                        continue;
+                    }
+                    if (dg >= 2) hi = dg - 2;
+                    while (lo < hi) {  // first position in [lo, hi] that does not precede the point
                         const int mid = (lo + hi) >> 1;
                         if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
                             lo = mid + 1;
