@@ -97,8 +97,9 @@ int egdst_destroy(egdst_handle *h);
 /* Draw groups.  The draws of a handle are split into `ngroups` contiguous ranges whose per-period kernels are
  * enqueued on separate HIP streams (forked from and joined to the handle's stream), so that one draw with a long
  * sequential stretch -- the reference's guess generator re-bases point after point on some parameter draws --
- * holds up its own group only.  Results do not depend on the grouping.  Default: 1 below 1024 draws, 4 from there,
- * 8 from 2048 draws when the process runs with GPU_MAX_HW_QUEUES >= 10 (environment EGDST_GROUPS overrides).  At most 16. */
+ * holds up its own group only.  Results do not depend on the grouping.  Default with GPU_MAX_HW_QUEUES >= 10: 4 groups from
+ * 64 draws, 8 from 512; with fewer hardware queues: 4 groups from 1024 draws (environment EGDST_GROUPS overrides).
+ * At most 16. */
 int egdst_set_groups(egdst_handle *h, int ngroups);
 /* Physical geometry of the handle: rows per list and row stride of the device tables (egdst_device_tables). */
 int egdst_geometry(egdst_handle *h, int *rows_cap, int *table_stride);
