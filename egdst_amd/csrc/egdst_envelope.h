@@ -3,8 +3,10 @@
 // Restates envelop/funcvalue/linter2/thresholds/brsolve (egdst_solver.c:1165-1968) over SoA arrays:
 // the points are already sorted by (M asc, V desc, function asc) (comp1, :1570-1582) by the
 // rank-merge of the calling kernel; `rank[fstart[f]+k]` is the sorted position of the k-th point
-// of function f.  The walk itself is data-dependent and sequential (one lane); the recursion of
-// thresholds() is unrolled onto an explicit stack of pending (previous, entering) function pairs.
+// of function f.  The walk is data-dependent: one wave runs it, 64 sorted positions per step where nothing
+// irregular happens (env_walk_wave) and a wave-cooperative generic step at the events (env_step_wave); the plain
+// sequential restatement (env_step, env_crossing) is kept for the diagnostic build EGDST_SEQ_WALK.  The recursion
+// of thresholds() is unrolled onto an explicit stack of pending (previous, entering) function pairs.
 #pragma once
 #include "egdst_device.h"
 

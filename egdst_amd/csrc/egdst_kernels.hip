@@ -1,6 +1,6 @@
 // egdst_kernels.hip -- backward-induction DC-EGM solver and forward simulator for MI355X (gfx950).
 //
-// One backward period = four launches on one stream:
+// One backward period = four launches per draw group, each group on its own stream:
 //   k_probe     one wave per (draw, state, choice): the sequential head of the guess generator
 //               (adraw stage 0/1 and the zero-consumption resend, egdst_solver.c:955-1099) with
 //               each full expectation evaluated cooperatively by the 64 lanes (one lane per
@@ -8,6 +8,8 @@
 //   k_grid      one lane per remaining end-of-period asset point: closed-form log grid
 //               (egdst_solver.c:1110-1136) + the serial (next state, shock) loop of egmbellman
 //               (egdst_solver.c:494-574) + Euler inversion (:628-650);
+//   k_fixup     one workgroup per (draw, state, choice), idle unless a zero-consumption resend turned up inside the
+//               grid stage (:1080-1099): then the stream is regenerated in the reference's order;
 //   k_envelope  one workgroup per (draw, state): stop rule (:1100,1150), compaction, secondary
 //               envelope (:776-913), rank-merge sort + primary envelope (:1165-1550), saveoutput
 //               layout (:917-952);

@@ -137,6 +137,8 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 typedef void *hipEvent_t;
+typedef void *hipGraphExec_t;
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }

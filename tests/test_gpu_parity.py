@@ -198,3 +198,20 @@ def test_draw_groups_and_compact_capacity_do_not_change_results():
             a, b = s.solution(i), base.solution(i)
             assert np.array_equal(a.len, b.len) and np.array_equal(a.M, b.M) and np.array_equal(a.V, b.V, equal_nan=True)
         s.close()
+
+
+def test_draws_with_many_monotone_pieces_bit_exact():
+    """C2 draws with a high disutility of work fold the worker's choice list into dozens of monotone pieces: the
+    secondary envelope then walks 20-50 functions, which exercises the wave-cooperative generic step (a function per
+    lane, the reference's tie rules) and the range shortcuts of the rank-merge sort.  Tables bit for bit."""
+    m, gen = workloads.c2()
+    P = gen(64)[[57, 13, 11, 37]]
+    s = gpu_solve(m, P, keep_history=True)
+    orc = Oracle(m)
+    for i in range(len(P)):
+        ref = orc.solve(P[i])
+        sol = s.solution(i)
+        assert ref.rc == 0 and sol.status == 0
+        ok, rep = compare(sol, ref, 0.0, 0.0)
+        assert ok, (i, rep)
+        assert sol.nevals == ref.nevals
