@@ -155,7 +155,8 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            if (tj['workload'], tj['ndraw'], tj['rows_cap'], tj['kernel']) == (args.workload, ndraw, args.rows_cap, 'k_' + names[dom]):
+            if (tj['workload'], tj['ndraw'], tj['rows_cap'], tj['kernel'], tj['launches_per_step']) == (
+                    args.workload, ndraw, args.rows_cap, 'k_' + names[dom], int(klaunch[dom])):
                 traffic = tj['fetch_bytes_per_launch'] + tj['write_bytes_per_launch']
         except (OSError, KeyError, ValueError):
             pass

@@ -1118,7 +1118,10 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 // pass 0: launched with a small lcap so that two workgroups share a CU; a cell whose stream does not fit is left
 //         untouched and flagged in b.defer;  pass 1: launched with the large lcap, works on the flagged cells only
 //         (streams beyond that sort and walk in global memory);  pass 2: every cell, one launch (no deferral).
-__global__ void __launch_bounds__(ENV_BS) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
+#ifndef ENV_MINW
+#define ENV_MINW 1
+#endif
+__global__ void __launch_bounds__(ENV_BS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
 {
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_BS];
