@@ -899,13 +899,20 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
 // LDS regions (lcap entries each): R1, R2, R3 doubles; Lf, Lp ints.  Keys are staged in R1 (M) and R2 (V); the
 // sorted stream ends up as M in R2, V in R3 and C in R1 (a key region is recycled as soon as every thread has
 // read it), so a point costs 36 B of LDS including its class word.
+// The rank of a point is the sum over the functions of "how many of its points precede this one", and that count is
+// also all the envelope walk's pre-classification needs to evaluate the function at the point (env_preclass): when
+// the lists are in order the class word is computed right here from the staged keys (cls != nullptr; *fused = 1),
+// `ana(g, x)` being the value of g before its first point (env_analytic / -inf).
+template <class ANA>
 static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const double *im, const double *ic,
                                                         const double *iv, const int *ifn, const eg_ldsi *fstart,
                                                         const eg_ldsi *dims, eg_ldsd *R1, eg_ldsd *R2, eg_ldsd *R3,
-                                                        eg_ldsi *Lf, eg_ldsi *Lp, int lcap, int *sh, int *oob)
+                                                        eg_ldsi *Lf, eg_ldsi *Lp, int lcap, int *sh, int *oob,
+                                                        eg_ldsi *cls, int *fused, ANA ana)
 {
     eg_ldsd *Km = R1, *Kv = R2, *Lm = R2, *Lv = R3, *Lc = R1;
     const int tid = threadIdx.x;
+    *fused = 0;
     for (int i = tid; i < npts; i += ENV_BS) {
         Km[i] = im[i];
         Kv[i] = iv[i];
@@ -919,11 +926,22 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
     while (P < npts) P <<= 1;
     if (bad && P > lcap) bad = 2;  // no room for the padded network: counting ranks instead
     if (bad != 1) {
+        double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
+        if (!bad && cls) {
+            for (int g = 0; g < nf; g++)
+                if (dims[g] > 0) {
+                    const double last = Km[fstart[g] + dims[g] - 1];
+                    if (last < kbound) kbound = last;
+                }
+            *fused = 1;
+        }
         for (int i = tid; i < npts; i += ENV_BS) {
             const double m = Km[i], v = Kv[i];
             const int f = ifn[i];
             int r = 0;
             if (!bad) {
+                int w = 0;          // class word of this point (env_preclass)
+                bool force = false;
                 for (int g = 0; g < nf; g++) {
                     const int dg = dims[g];
                     if (dg <= 0) continue;
@@ -932,28 +950,54 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
                         r += i - s0;
                         continue;
                     }
-                    // the list is in comp1 order: most lists lie entirely on one side of the point (pieces of a
-                    // folded choice list overlap only near the kinks), which two or three key reads settle
-                    if (!pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) continue;  // none of g precedes the point
-                    int lo = 1, hi = dg;
-                    if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i)) {
-                        r += dg;  // all of g precede it
-                        continue;
-                    }
-                    hi = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
-                    if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i)) {
-                        r += dg - 1;
-                        continue;
-                    }
-                    if (dg >= 2) hi = dg - 2;
-                    while (lo < hi) {  // first position in [lo, hi] that does not precede the point
-                        const int mid = (lo + hi) >> 1;
-                        if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
-                            lo = mid + 1;
-                        else
-                            hi = mid;
+                    // lo = points of g that precede this one.  The list is in comp1 order and most lists lie entirely
+                    // on one side of the point (pieces of a folded choice list overlap only near the kinks), which
+                    // two or three key reads settle
+                    int lo = 0;
+                    if (pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) {
+                        if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i))
+                            lo = dg;
+                        else if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i))
+                            lo = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
+                        else {
+                            int hi = dg >= 2 ? dg - 2 : dg - 1;
+                            lo = 1;
+                            while (lo < hi) {  // first position in [lo, hi] that does not precede the point
+                                const int mid = (lo + hi) >> 1;
+                                if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                        }
                     }
                     r += lo;
+                    if (cls && !force) {
+                        if (lo >= dg)
+                            force = true;  // g has no point ahead: cannot happen below the bound
+                        else {
+                            double t;
+                            if (lo >= 1) {  // env_fn_cnt on the staged keys: the segment between g's points lo-1 and lo
+                                const double ga = Km[s0 + lo - 1], gb = Km[s0 + lo], fa = Kv[s0 + lo - 1], fb = Kv[s0 + lo];
+                                if (m == ga)
+                                    t = fa;
+                                else if (m < ga || m > gb)
+                                    t = -INFINITY;
+                                else
+                                    t = fb * (m - ga) / (gb - ga) + fa * (gb - m) / (gb - ga);
+                            } else
+                                t = ana(g, m);
+                            if (v < t) w |= 1;
+                            if (t < v && nf <= 29) w |= (2 << g);
+                        }
+                    }
+                }
+                if (cls) {
+                    if (force || !(m < kbound))
+                        w = ENV_CLS_FORCE;
+                    else if (nf > 29)
+                        w |= ENV_CLS_NOMASK;
+                    if (r >= 0 && r < npts) cls[r] = w;
                 }
             } else {
                 for (int j = 0; j < npts; j++)
@@ -1065,7 +1109,7 @@ template <bool L>
 static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
                                                 const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
                                                 const typename EgMem<L>::I *f, const typename EgMem<L>::I *posl,
-                                                typename EgMem<L>::I *cls, int *err, int *n, int *nth)
+                                                typename EgMem<L>::I *cls, int *err, int *n, int *nth, int classified)
 {
     EnvCtxT<L> e;
     e.E = E;
@@ -1104,8 +1148,36 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.oi = e.oj = 0;
     e.lastg = 0;
     e.pm = -1;
-    env_preclass(e, j.npts, cls, (int)threadIdx.x, ENV_BS);
+#ifdef EGDST_STAMPS
+    const unsigned long long pc0_ = wall_clock64();
+#endif
+    if (!classified) env_preclass(e, j.npts, cls, (int)threadIdx.x, ENV_BS);  // (else done by the sort)
     __syncthreads();
+#ifdef EGDST_EMU
+    if (classified && getenv("EGDST_VERIFY_CLS")) {  // harness: the sort's class words must equal env_preclass's
+        static int chk[8192];
+        static int nbad;
+        if (threadIdx.x == 0) nbad = 0;
+        __syncthreads();
+        if (j.npts <= 8192) {
+            env_preclass(e, j.npts, (typename EgMem<L>::I *)chk, (int)threadIdx.x, ENV_BS);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int p = 0; p < j.npts; p++)
+                    if (chk[p] != cls[p] && nbad++ < 5)
+                        fprintf(stderr, "CLS MISMATCH it=%d ist=%d sec=%d p=%d/%d f=%d sort=%08x preclass=%08x\n", j.it, j.ist, j.sec_id, p,
+                                j.npts, (int)f[p], (unsigned)cls[p], (unsigned)chk[p]);
+                if (nbad) fprintf(stderr, "CLS MISMATCHES %d\n", nbad);
+                static long nver = 0;
+                if (++nver % 50 == 0) fprintf(stderr, "cls verified on %ld walks\n", nver);
+            }
+            __syncthreads();
+        }
+    }
+#endif
+#ifdef EGDST_STAMPS
+    if (threadIdx.x == 0 && j.dbg) atomicAdd((unsigned long long *)j.dbg + 1, wall_clock64() - pc0_);
+#endif
     if ((int)threadIdx.x < WAVE) {
         env_walk_wave(e, j.npts);
         *err = e.err;
@@ -1423,13 +1495,27 @@ __global__ void __launch_bounds__(ENV_BS, ENV_MINW) k_envelope(Batch b, int it, 
         }
         // ---- common: sort the stream (comp1 order) and walk it ----------------------------------------
         if (job.npts <= lcap) {
+            // value of function g before its first point (env_analytic / env_evf of the walk)
+            const int sec_id_ = job.sec_id;
+            const double sec_ev_ = job.sec_ev;
+            auto ana = [&](int g, double x) -> double {
+                const double ev = (sec_id_ >= 0) ? (g == sec_id_ ? sec_ev_ : -INFINITY) : s_evfa0[g];
+                if (ev == -INFINITY) return -INFINITY;
+                ms_pv cv;
+                cv.it = it;
+                cv.ist = ist;
+                cv.id = g;
+                cv.cash = cv.savings = cv.shock = 0;
+                return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
+            };
+            int fused = 0;
             const eg_ldsi *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
-                                               sh, &s_oob);
+                                               sh, &s_oob, Lq, &fused, ana);
             STAMP(3);  // LDS sort
             if (s_oob) ENV_FAIL(2704);
             {
                 int we = 0, wn = 0, wm = 0;
-                run_walk<true>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm);  // sorted M, C, V
+                run_walk<true>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm, fused);  // sorted M, C, V
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         } else if (pass == 0) {
@@ -1446,7 +1532,7 @@ __global__ void __launch_bounds__(ENV_BS, ENV_MINW) k_envelope(Batch b, int it, 
             if (s_oob) ENV_FAIL(2714);
             {
                 int we = 0, wn = 0, wm = 0;  // (sF is free once the stream is sorted: it holds the classification words)
-                run_walk<false>(&E, job, qM, qC, qV, qF, rank, sF, &we, &wn, &wm);
+                run_walk<false>(&E, job, qM, qC, qV, qF, rank, sF, &we, &wn, &wm, 0);
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         }
