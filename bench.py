@@ -172,6 +172,7 @@ def main():
                 'parallelism': 'draws sharded over %d rank(s), no data-path collective' % world},
             'evals_per_step': evals_all, 'failed_draws_rank0': int((status != 0).sum()),
             'single_solve_ms': single_ms, 'capacity_retries': solver.capacity_retries,
+            'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())),
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
             'kernel_ms_per_step': {n: float(v) for n, v in zip(names, kms)},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + names[dom], 'achieved': achieved, 'peak': 8000.0,

@@ -33,7 +33,11 @@ struct Geom {
 // Device-resident state of a batch (all pointers are device memory).
 struct Batch {
     Geom g;
-    int draw0;           // first draw of the group this launch works on (groups run on their own streams)
+    int draw0;           // first schedule slot of the group this launch works on (groups run on their own streams)
+    const int *order;    // [ndraw] schedule: slot -> draw (identity until the host re-balances, egdst_host.inc)
+    int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
+    int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
+    unsigned *work;      // [ndraw] re-basing calls of the draw's guess streams in this solve (straggler detection)
     const double *par;   // [ndraw][MS_NPARAM]
     const double *qw;    // [ny] weights
     const double *qz;    // [ny] standard-normal nodes (Acklam of the GL abscissae, egdst_solver.c:164)

@@ -29,7 +29,9 @@
 #define ENV_BS 256
 #endif
 #define EG_WAVE WAVE
+#ifndef EG_FIX_LROWS
 #define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
+#endif
 #define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
@@ -73,7 +75,7 @@ static __device__ __forceinline__ size_t eg_cand(const Batch &b, int draw, int i
 __global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
 {
     const int combo = blockIdx.y;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     const int i = blockIdx.x * GRID_BS + threadIdx.x;
     if (b.status[draw]) return;
     ms_env E = eg_env(b, draw);
@@ -379,6 +381,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         __syncthreads();
     }
     int last_cnt = 0;  // evaluations of the most recent expectation
+    int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
     for (;;) {
         // ---- next guess -------------------------------------------------------------------
@@ -393,6 +396,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 // (:963-978) ends the stream.  Account for those calls instead of executing them.
                 const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still evaluate
                 nev += k * last_cnt;
+                skipped = k + 1;  // (accounted for, not executed: no straggler work)
                 ncalls = b.g.ngridmax;
                 break;
             }
@@ -661,6 +665,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     if (lead && full && getenv("EGDST_TRACE_FIXUP"))
         fprintf(stderr, "fixup end it=%d id=%d ncalls=%d ngen=%d np=%d last=%g M=%g nev=%d\n", it, id, ncalls, ngenerated, np, last, M, nev);
 #endif
+    // re-basing calls of this stream beyond the regular ones: the host schedules draws with many of them apart
+    if (lead && ncalls - skipped > (full ? ntogenerate : 0) + 64)
+        atomicAdd(&b.work[draw], (unsigned)(ncalls - skipped - (full ? ntogenerate : 0)));
     if (lead) {
         P->active = 1;
         P->seq = full;
@@ -683,19 +690,21 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
 __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
 {
     const int combo = blockIdx.x;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
     eg_adraw_cycle<1, 0>(b, it, draw, ist, id);
 }
 
-// After k_grid: does the stream of (draw, ist, id) contain a zero-consumption signal among the points the
-// generator would actually request?  If so redo that stream sequentially (exactly as the reference does).
-__global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
+// After k_grid: does the stream of (draw, ist, id) contain a zero-consumption signal among the points the generator
+// would actually request?  k_fixup_scan (one wave per stream, no LDS) lists those streams; k_fixup (a small grid of
+// 4-wave workgroups with the LDS table buffer) redoes each listed stream sequentially, exactly as the reference does.
+// `cnt` is this (group, period)'s counter, `list` the group's list (one entry per stream at most).
+__global__ void __launch_bounds__(WAVE) k_fixup_scan(Batch b, int it, int *cnt, int *list)
 {
     const int combo = blockIdx.x;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
-    const int lane = threadIdx.x & (WAVE - 1);  // every wave of the workgroup takes the same decisions
+    const int lane = threadIdx.x & (WAVE - 1);
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
     if (!P.active || !P.grid) return;
     const size_t co = eg_cand(b, draw, ist, id);
@@ -715,11 +724,21 @@ __global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
         }
         if (resend || ms) break;
     }
-    if (!resend) return;
+    if (resend && lane == 0) list[atomicAdd((unsigned *)cnt, 1u)] = combo;
+}
+
+__global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it, const int *cnt, const int *list)
+{
+    const int n = *cnt;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int combo = list[k];
+        const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
 #ifdef EGDST_EMU
-    if (threadIdx.x == 0 && getenv("EGDST_TRACE_FIXUP")) fprintf(stderr, "fixup it=%d draw=%d ist=%d id=%d\n", it, draw, ist, id);
+        if (threadIdx.x == 0 && getenv("EGDST_TRACE_FIXUP")) fprintf(stderr, "fixup it=%d draw=%d ist=%d id=%d\n", it, draw, ist, id);
 #endif
-    eg_adraw_cycle<FIX_BS / WAVE, 1>(b, it, draw, ist, id);
+        eg_adraw_cycle<FIX_BS / WAVE, 1>(b, it, draw, ist, id);
+        __syncthreads();  // the LDS buffers of the stream generator are reused by the next listed stream
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -727,7 +746,7 @@ __global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it)
 __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
 {
     const int combo = blockIdx.y;
-    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.draw0 + combo / (MS_ND * MS_NST);
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
     if (b.status[draw]) return;
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
@@ -1202,7 +1221,7 @@ __global__ void __launch_bounds__(ENV_BS, ENV_MINW) k_envelope(Batch b, int it, 
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
-    const int ist = blockIdx.x % MS_NST, draw = b.draw0 + blockIdx.x / MS_NST;
+    const int ist = blockIdx.x % MS_NST, draw = b.order[b.draw0 + blockIdx.x / MS_NST];
     const int tid = threadIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;

@@ -31,7 +31,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups']
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -65,6 +65,8 @@ class ModelLibrary:
         L.egdst_create_compact.argtypes = [C.POINTER(EgdstDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.POINTER(C.c_void_p)]
         L.egdst_set_groups.argtypes = [C.c_void_p, C.c_int]
+        L.egdst_set_adaptive.argtypes = [C.c_void_p, C.c_int]
+        L.egdst_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_objective.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.egdst_get_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -176,6 +178,22 @@ class Solver:
     def set_groups(self, ngroups):
         """Split the draws into `ngroups` ranges that run on their own streams (egdst_set_groups)."""
         self.lib.check(self.lib.lib.egdst_set_groups(self.h, int(ngroups)))
+
+    def set_adaptive(self, on=True):
+        """History-based scheduling of straggler draws on lanes of their own (egdst_set_adaptive)."""
+        self.lib.check(self.lib.lib.egdst_set_adaptive(self.h, int(bool(on))))
+
+    def schedule(self):
+        """(regular groups, straggler lanes, straggler draws) of the next solve"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.lib.check(self.lib.lib.egdst_get_schedule(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def work(self):
+        """re-basing calls per draw in the last solve (egdst_get_work)"""
+        out = np.zeros(self.ndraw, dtype=np.uint32)
+        self.lib.check(self.lib.lib.egdst_get_work(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def geometry(self):
         """(physical rows per list, row stride of the device tables)"""

@@ -101,6 +101,15 @@ int egdst_destroy(egdst_handle *h);
  * 64 draws, 8 from 512, and 16 from 1024 draws with >= 20 queues; with the runtime's default of 4 hardware queues:
  * 4 groups from 1024 draws (environment EGDST_GROUPS overrides).  At most 32. */
 int egdst_set_groups(egdst_handle *h, int ngroups);
+/* History-based scheduling (on by default with more than one group): after a solve, the draws whose guess streams
+ * re-based more than 1000 times (degenerate parameter draws: one such stream is ~75 ms of strictly sequential work)
+ * are scheduled on up to 8 extra streams of their own in the next solves, as far as hardware queues are left,
+ * so that they hold up each other instead of a whole group.  Results do not depend on it. */
+int egdst_set_adaptive(egdst_handle *h, int on);
+/* Current schedule: regular groups, extra straggler lanes, draws currently treated as stragglers. */
+int egdst_get_schedule(egdst_handle *h, int *groups, int *lanes, int *stragglers);
+/* Re-basing calls of every draw's guess streams in the last solve (the straggler measure). */
+int egdst_get_work(egdst_handle *h, unsigned *out /* [ndraw] */);
 /* Physical geometry of the handle: rows per list and row stride of the device tables (egdst_device_tables). */
 int egdst_geometry(egdst_handle *h, int *rows_cap, int *table_stride);
 

@@ -118,6 +118,7 @@ static inline int atomicCAS(int *p, int cmp, int val)
     if (old == cmp) *p = val;
     return old;
 }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __sync_fetch_and_add(p, v); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
 {
     unsigned long long old = *p;

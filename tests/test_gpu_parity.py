@@ -215,3 +215,27 @@ def test_draws_with_many_monotone_pieces_bit_exact():
         ok, rep = compare(sol, ref, 0.0, 0.0)
         assert ok, (i, rep)
         assert sol.nevals == ref.nevals
+
+
+def test_history_based_schedule_does_not_change_results():
+    """After a solve the handle moves draws with degenerate guess streams to lanes of their own (egdst_set_adaptive);
+    the next solves must give the same per-draw status, evaluation counts and objective values."""
+    m, gen = workloads.c2()
+    P = gen(1024)[[0, 550, 3, 348, 5, 7, 11, 13]]
+    lib = build.build_model(m)
+    s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=False)
+    s.set_groups(2)
+    s.set_params(P)
+    s.solve(raise_on_error=False)
+    first = (s.status()[0].copy(), s.evals()[1].copy(), s.objective().copy())
+    assert s.work()[1] > 1000 and s.work()[3] > 1000          # the two degenerate draws were noticed
+    groups, lanes, nstrag = s.schedule()
+    assert nstrag == 2
+    for _ in range(2):
+        s.solve(raise_on_error=False)
+        assert np.array_equal(s.status()[0], first[0]) and np.array_equal(s.evals()[1], first[1])
+        assert np.array_equal(s.objective(), first[2], equal_nan=True)
+    s.set_adaptive(False)
+    assert s.schedule()[2] == 0
+    s.solve(raise_on_error=False)
+    assert np.array_equal(s.status()[0], first[0]) and np.array_equal(s.evals()[1], first[1])
