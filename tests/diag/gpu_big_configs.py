@@ -1,7 +1,7 @@
 """GPU check of the large configurations of SURVEY.md §8d against the oracle (first draw), plus batch timing.
-    python tests/gpu_big_configs.py C4 [ndraw]      Deaton stress, T=80, 65 536 points, 21 nodes
-    python tests/gpu_big_configs.py C5r [ndraw]     8-state retirement at the size the oracle is pinned on (T=60, n=2000)
-    python tests/gpu_big_configs.py C5 [ndraw]      8-state retirement, T=100, 32 768 points, 15 nodes
+    python tests/diag/gpu_big_configs.py C4 [ndraw]      Deaton stress, T=80, 65 536 points, 21 nodes
+    python tests/diag/gpu_big_configs.py C5r [ndraw]     8-state retirement at the size the oracle is pinned on (T=60, n=2000)
+    python tests/diag/gpu_big_configs.py C5 [ndraw]      8-state retirement, T=100, 32 768 points, 15 nodes
 """
 import sys
 import time

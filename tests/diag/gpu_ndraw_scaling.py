@@ -1,5 +1,5 @@
 """Diagnostic: batched-step time vs number of draws and vs the physical row capacity.
-    python tests/gpu_ndraw_scaling.py <rows_cap|0> <ndraw>..."""
+    python tests/diag/gpu_ndraw_scaling.py <rows_cap|0> <ndraw>..."""
 import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np

@@ -39,7 +39,7 @@ SCALED = {
     'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
     # 3 x 1400 points do not fit the LDS stream buffers: exercises the global-memory sort and walk
     'occ3_n1400_global_path': lambda: examples.occ3(T=12, ngridm=1400, ngridmax=14000, nthrhmax=1400, ny=10),
-    # BASELINE configs[3] and [4] at the sizes SURVEY.md §8d pins them on (C5 at T=60, n=2000; tests/gpu_big_configs.py
+    # BASELINE configs[3] and [4] at the sizes SURVEY.md §8d pins them on (C5 at T=60, n=2000; tests/diag/gpu_big_configs.py
     # runs C5 at T=100, n=32768 against the oracle as well: bit-exact, 216 s of CPU)
     'C4_deaton_T80_n65536_ny21': lambda: workloads.c4()[0],
     'C5_8states_T60_n2000': lambda: workloads.c5(ngridm=2000, T=60)[0],
