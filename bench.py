@@ -145,7 +145,7 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # single-solve latency (one draw) for the "full backward-induction wall time" half of the metric
         single_ms = None
-        if not args.no_single_solve:
+        if not args.no_single_solve and world == 1:
             s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
             s1.set_params(mine[:1])
             s1.solve()
@@ -185,7 +185,7 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
                          'launches': int(klaunch[dom])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(model, mine)
             out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']
             if single_ms:
