@@ -239,3 +239,36 @@ def test_history_based_schedule_does_not_change_results():
     assert s.schedule()[2] == 0
     s.solve(raise_on_error=False)
     assert np.array_equal(s.status()[0], first[0]) and np.array_equal(s.evals()[1], first[1])
+
+
+EDGE = {
+    'single_period_T_equals_t0': lambda: examples.deaton2(T=1, t0=1),
+    'two_periods_8_points': lambda: examples.retirement2(T=2, ngridm=8),
+    'three_points_per_choice': lambda: examples.retirement2(T=3, ngridm=3, ngridmax=40),
+    'one_quadrature_node_8_states': lambda: examples.retirement8(T=2, ngridm=12, ny=1),
+    'ngridmax_just_above_ngridm': lambda: examples.occ3(T=6, ngridm=30, ngridmax=31),
+}
+
+
+@pytest.mark.parametrize('name', sorted(EDGE))
+def test_edge_sizes_bit_exact(name):
+    m = EDGE[name]()
+    s = gpu_solve(m)
+    sol, ref = s.solution(0), Oracle(m).solve()
+    assert ref.rc == 0 and sol.status == 0, (sol.status, sol.err, ref.err)
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    assert sol.nevals == ref.nevals
+
+
+@pytest.mark.parametrize('nthrhmax', [1, 2])
+def test_threshold_capacity_error_matches_the_reference(nthrhmax):
+    """'Not enough space for thresholds' (egdst_solver.c:1327,1891): same failing period, same message, and the
+    periods solved before it are exported exactly as the oracle's (the reference returns partial cells, :237)."""
+    m = examples.retirement2(T=8, ngridm=60, nthrhmax=nthrhmax)
+    s = gpu_solve(m)
+    sol, ref = s.solution(0), Oracle(m).solve()
+    assert ref.rc != 0 and sol.status == 20
+    assert sol.err.strip() == ref.err.strip()
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
