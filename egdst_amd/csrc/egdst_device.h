@@ -35,6 +35,7 @@ struct Batch {
     Geom g;
     int draw0;           // first schedule slot of the group this launch works on (groups run on their own streams)
     const int *order;    // [ndraw] schedule: slot -> draw (identity until the host re-balances, egdst_host.inc)
+    int *negflag;        // [(draw*MS_NST+ist)*MS_ND+id] a grid point of the stream signalled c1<=0 (set by k_grid)
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
     unsigned *work;      // [ndraw] re-basing calls of the draw's guess streams in this solve (straggler detection)

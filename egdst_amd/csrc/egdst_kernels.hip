@@ -692,6 +692,7 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
     const int combo = blockIdx.x;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
+    if (threadIdx.x == 0) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 0;
     eg_adraw_cycle<1, 0>(b, it, draw, ist, id);
 }
 
@@ -705,6 +706,7 @@ __global__ void __launch_bounds__(WAVE) k_fixup_scan(Batch b, int it, int *cnt, 
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
     const int lane = threadIdx.x & (WAVE - 1);
+    if (!b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id]) return;  // no grid point of the stream signalled c1<=0
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
     if (!P.active || !P.grid) return;
     const size_t co = eg_cand(b, draw, ist, id);
@@ -763,6 +765,7 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
     const LaneEval r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
     const size_t o = eg_cand(b, draw, ist, id) + n;
+    if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
     b.cCnt[o] = r.cnt;
     b.cSt[o] = r.status;
     b.cR[o] = r.R;
