@@ -26,8 +26,14 @@
 #ifndef WAVE  // the sanitizer harness (tests/cpu_emu) overrides these
 #define WAVE 64
 #define GRID_BS 256
-#define ENV_BS 256
+#define ENV_MAXBS 512  // most threads of a k_envelope workgroup (what it is compiled for: <= 256 VGPRs)
+#else
+#define ENV_MAXBS ENV_BS_EMU
 #endif
+// k_envelope runs with 256 threads per workgroup in big batches and with 512 when the batch leaves CUs idle (its
+// sort, compaction and classification phases scale with the threads, the walk is one wave either way): measured on
+// C2, a single solve 18 -> 16 ms with 512 threads, a 4096-draw batch 332 -> 350 ms.  Device code reads the size.
+#define ENV_BS ((int)blockDim.x)
 #define EG_WAVE WAVE
 #ifndef EG_FIX_LROWS
 #define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
@@ -1215,10 +1221,10 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifndef ENV_MINW
 #define ENV_MINW 1
 #endif
-__global__ void __launch_bounds__(ENV_BS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
+__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
 {
     EG_DYN_LDS(dynlds);
-    __shared__ int sh[ENV_BS];
+    __shared__ int sh[ENV_MAXBS];
     __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
     __shared__ int s_stack[2 * (ENV_SMALLF + 2)];
     __shared__ double s_evfa0[MS_ND];
