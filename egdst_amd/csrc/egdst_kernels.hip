@@ -243,12 +243,16 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
 // lane redundantly, so that sums and early exits equal the serial loop (egdst_solver.c:494-574).
 // Returns 0 normal, 1 c1<=0, 2 evf=-inf, <0 hard error (-code).  brk_* describe the break point.
 // TT: table type; `lt` (TabL only): the next-period table of state 0 staged in LDS by the caller (MS_NST == 1).
-template <class TT>
+// GW: lanes that share one guess (a whole wave for k_probe / k_fixup; 16 for k_grid_wide, where the groups of a wave
+// work on different guesses and may leave the accumulation loop at different shock nodes -- every shuffle reads a
+// lane of the own group, which is active whenever the reader is).
+template <class TT, int GW = WAVE>
 static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
                                           double savings, int keep, double *rhs_o, double *evf_o, int *nev,
                                           int *brk_ist, double *brk_shock, double *brk_cash, const TT *lt)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = threadIdx.x & (GW - 1);                          // position in the group
+    const int gbase = (threadIdx.x & (WAVE - 1)) - lane;            // first lane of the group within the wave
     const int ny = b.g.ny;
     double rhs = 0, evf = 0, checksum = 0, c1_last = 1.0;
     int status = 0, terr = 0, cnt = 0;
@@ -278,7 +282,7 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
         }
         if (t.len < 2) return -10;
         if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
-        for (int base = 0; base < niy && status == 0; base += WAVE) {
+        for (int base = 0; base < niy && status == 0; base += GW) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
             if (iy < niy) {
@@ -295,29 +299,29 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
                 shock = nl.shock;
                 cash = nl.cash;
             }
-            if (__any(terr)) return -25;
-            const int nl_ = min(WAVE, niy - base);
+            if (GW == WAVE ? __any(terr) : (((__ballot(terr) >> gbase) & ((1ull << (GW & 63)) - 1ull)) != 0ull)) return -25;
+            const int nl_ = min(GW, niy - base);
             for (int l = 0; l < nl_; l++) {  // ordered accumulation
-                const double p = __shfl(pr1, l);
+                const double p = __shfl(pr1, gbase + l);
                 if (p == 0.0) continue;
                 checksum += p;
                 cnt++;
-                c1_last = __shfl(c1, l);
+                c1_last = __shfl(c1, gbase + l);
                 if (c1_last <= 0) {
                     status = 1;
                     *brk_ist = ist1;
-                    *brk_shock = __shfl(shock, l);
-                    *brk_cash = __shfl(cash, l);
+                    *brk_shock = __shfl(shock, gbase + l);
+                    *brk_cash = __shfl(cash, gbase + l);
                     break;
                 }
-                rhs += __shfl(t_rhs, l);
+                rhs += __shfl(t_rhs, gbase + l);
                 if (keep == 1) {
-                    evf += __shfl(t_evf, l);
+                    evf += __shfl(t_evf, gbase + l);
                     if (evf == -INFINITY) {
                         status = 2;
                         *brk_ist = ist1;
-                        *brk_shock = __shfl(shock, l);
-                        *brk_cash = __shfl(cash, l);
+                        *brk_shock = __shfl(shock, gbase + l);
+                        *brk_cash = __shfl(cash, gbase + l);
                         break;
                     }
                 }
@@ -772,6 +776,65 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
     const LaneEval r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
     const size_t o = eg_cand(b, draw, ist, id) + n;
     if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
+    b.cCnt[o] = r.cnt;
+    b.cSt[o] = r.status;
+    b.cR[o] = r.R;
+    b.cM[o] = r.M;
+    if (r.status == 0) {
+        b.cC[o] = r.C;
+        b.cV[o] = r.V;
+    }
+}
+
+// k_grid for small batches: 16 lanes per grid point, a lane per shock node (eg_wave_expectation with groups of 16),
+// so that a solve that leaves the GPU mostly idle does not spend 20 serial shock terms per point: same arithmetic and
+// the same order of accumulation as eg_lane_eval, 62 -> 20 us per period on a single C2 draw.
+#ifdef EGDST_EMU
+#define EG_GW WAVE        // the harness cannot diverge inside a wave: one group per wave
+#define EG_GRIDW_BS WAVE
+#else
+#define EG_GW 16
+#define EG_GRIDW_BS 256
+#endif
+__global__ void __launch_bounds__(EG_GRIDW_BS) k_grid_wide(Batch b, int it)
+{
+    const int combo = blockIdx.y;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
+    const int n = (blockIdx.x * EG_GRIDW_BS + (int)threadIdx.x) / EG_GW + 1;  // the group's grid point
+    if (b.status[draw]) return;
+    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    if (!P.active || !P.grid || n >= b.g.ngridm) return;  // (whole groups leave together)
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = id;
+    cur.cash = cur.savings = cur.shock = 0;
+    GridLims L;
+    L.lim1 = P.lim1, L.lim2 = P.lim2, L.lim3 = P.lim3, L.lim3p = P.lim3p, L.k3 = P.k3, L.ntogenerate = P.ntogenerate;
+    const double A = eg_grid_A(&E, &cur, L, 0, P.A0, n);
+    const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+    double rhs = 0, evf = 0, bshock = 0, bcash = 0;
+    int cnt = 0, bist = 0;
+    const int st = eg_wave_expectation<Tab, EG_GW>(b, &E, slot1, draw, &cur, A, 1, &rhs, &evf, &cnt, &bist, &bshock, &bcash,
+                                                   (const Tab *)nullptr);
+    if ((threadIdx.x & (EG_GW - 1)) != 0) return;
+    LaneEval r;  // what eg_lane_eval reports for the point
+    r.status = st;
+    r.cnt = cnt;
+    if (st == 0) {
+        rhs *= ms_discount(&E, &cur);
+        r.M = A + ms_utility_marginal_inverse(&E, &cur, rhs);
+        r.C = r.M - A;
+        r.V = ms_utility(&E, &cur, r.C) + ms_discount(&E, &cur) * evf;
+        r.R = r.M;
+    } else {
+        r.M = NAN;
+        r.C = r.V = 0;
+        r.R = (st == 1) ? b.g.a0 - 1 : bcash;
+    }
+    const size_t o = eg_cand(b, draw, ist, id) + n;
+    if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;
     b.cCnt[o] = r.cnt;
     b.cSt[o] = r.status;
     b.cR[o] = r.R;
