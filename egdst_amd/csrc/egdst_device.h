@@ -145,6 +145,7 @@ MS_FN double eg_shock_uniform(double u, double mu, double sigma)
 #endif
 typedef EG_LDS_AS double eg_ldsd;
 typedef EG_LDS_AS int eg_ldsi;
+typedef EG_LDS_AS unsigned short eg_ldss;  // sorted positions and function ids of an LDS-resident stream (< 65536)
 
 // ---- bracket search + interpolation (egdst_lib.c:123-206) -----------------------------------
 // kind 0: bracket for interpolation/extrapolation; kind 1: last threshold <= x.

@@ -22,18 +22,20 @@
 template <bool L> struct EgMem {
     typedef double D;
     typedef int I;
+    typedef int S;  // function ids and sorted positions
 };
 template <> struct EgMem<true> {
     typedef eg_ldsd D;
     typedef eg_ldsi I;
+    typedef eg_ldss S;  // 16 bits in LDS: 32 B per point instead of 36
 };
 
 template <bool L> struct EnvCtxT {
     const ms_env *E;
     int it, ist, nf;
     const typename EgMem<L>::D *m, *c, *v;  // sorted points
-    const typename EgMem<L>::I *f;
-    const typename EgMem<L>::I *rank;       // position lists
+    const typename EgMem<L>::S *f;
+    const typename EgMem<L>::S *rank;       // position lists
     const eg_ldsi *fstart;
     eg_ldsi *dims, *cur, *mark;
     const typename EgMem<L>::I *cls;  // per sorted position: pre-classification word (env_preclass)
@@ -763,7 +765,7 @@ template <bool L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e,
 template <bool L> static __device__ __forceinline__ int env_count_before(const EnvCtxT<L> &e, int j, int p)
 {
     // number of points of function j at sorted positions < p (the position list of j is ascending)
-    const typename EgMem<L>::I *lst = e.rank + e.fstart[j];
+    const typename EgMem<L>::S *lst = e.rank + e.fstart[j];
     int lo = 0, hi = e.dims[j];
     while (lo < hi) {
         int mid = (lo + hi) >> 1;

@@ -989,16 +989,16 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
 // Returns the position lists (rank[fstart[f]+k] = sorted position of the k-th point of f).
 // LDS regions (lcap entries each): R1, R2, R3 doubles; Lf, Lp ints.  Keys are staged in R1 (M) and R2 (V); the
 // sorted stream ends up as M in R2, V in R3 and C in R1 (a key region is recycled as soon as every thread has
-// read it), so a point costs 36 B of LDS including its class word.
+// read it), so a point costs 32 B of LDS including its class word and the 16-bit function id and position.
 // The rank of a point is the sum over the functions of "how many of its points precede this one", and that count is
 // also all the envelope walk's pre-classification needs to evaluate the function at the point (env_preclass): when
 // the lists are in order the class word is computed right here from the staged keys (cls != nullptr; *fused = 1),
 // `ana(g, x)` being the value of g before its first point (env_analytic / -inf).
 template <class ANA>
-static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const double *im, const double *ic,
+static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const double *im, const double *ic,
                                                         const double *iv, const int *ifn, const eg_ldsi *fstart,
                                                         const eg_ldsi *dims, eg_ldsd *R1, eg_ldsd *R2, eg_ldsd *R3,
-                                                        eg_ldsi *Lf, eg_ldsi *Lp, int lcap, int *sh, int *oob,
+                                                        eg_ldss *Lf, eg_ldss *Lp, int lcap, int *sh, int *oob,
                                                         eg_ldsi *cls, int *fused, ANA ana)
 {
     eg_ldsd *Km = R1, *Kv = R2, *Lm = R2, *Lv = R3, *Lc = R1;
@@ -1118,7 +1118,7 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
             } else {
                 Km[i] = INFINITY;
                 Kv[i] = -INFINITY;
-                Lf[i] = 0x7fffffff;
+                Lf[i] = 0xffff;  // (no function has this id: ENV_SMALLF < 65535)
             }
             Lp[i] = i;
         }
@@ -1148,7 +1148,7 @@ static __device__ __forceinline__ eg_ldsi *blk_sort_lds(int npts, int nf, const 
         __syncthreads();
     }
     // position lists from the sorted stream (Lp held input indices or ranks; both are consumed)
-    eg_ldsi *posl = Lp;
+    eg_ldss *posl = Lp;
     for (int g = 0; g < nf; g++) {
         if (dims[g] <= 0) continue;
         int carry = 0;
@@ -1199,7 +1199,7 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
 template <bool L>
 static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
                                                 const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
-                                                const typename EgMem<L>::I *f, const typename EgMem<L>::I *posl,
+                                                const typename EgMem<L>::S *f, const typename EgMem<L>::S *posl,
                                                 typename EgMem<L>::I *cls, int *err, int *n, int *nth, int classified)
 {
     EnvCtxT<L> e;
@@ -1277,7 +1277,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     }
 }
 
-// lcap: sorted points that fit the dynamic LDS (36 B each: sorted M/C/V, function id, position list, class word).
+// lcap: sorted points that fit the dynamic LDS (32 B each: sorted M/C/V, class word, 16-bit function id and position).
 // pass 0: launched with a small lcap so that two workgroups share a CU; a cell whose stream does not fit is left
 //         untouched and flagged in b.defer;  pass 1: launched with the large lcap, works on the flagged cells only
 //         (streams beyond that sort and walk in global memory);  pass 2: every cell, one launch (no deferral).
@@ -1341,7 +1341,8 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
     eg_ldsd *R1 = (eg_ldsd *)dynlds, *R2 = R1 + lcap, *R3 = R2 + lcap;
-    eg_ldsi *Lf = (eg_ldsi *)(R3 + lcap), *Lr = Lf + lcap, *Lq = Lr + lcap;
+    eg_ldsi *Lq = (eg_ldsi *)(R3 + lcap);            // class words
+    eg_ldss *Lf = (eg_ldss *)(Lq + lcap), *Lr = Lf + lcap;  // function ids, position lists
     eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
 
     WalkJob job;
@@ -1600,7 +1601,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
                 return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
             };
             int fused = 0;
-            const eg_ldsi *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
+            const eg_ldss *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
                                                sh, &s_oob, Lq, &fused, ana);
             STAMP(3);  // LDS sort
             if (s_oob) ENV_FAIL(2704);
