@@ -98,8 +98,8 @@ int egdst_destroy(egdst_handle *h);
  * enqueued on separate HIP streams (forked from and joined to the handle's stream), so that one draw with a long
  * sequential stretch -- the reference's guess generator re-bases point after point on some parameter draws --
  * holds up its own group only.  Results do not depend on the grouping.  Default with GPU_MAX_HW_QUEUES >= 10: 4 groups from
- * 64 draws, 8 from 512, and 16 from 1024 draws with >= 20 queues; with the runtime's default of 4 hardware queues:
- * 4 groups from 1024 draws (environment EGDST_GROUPS overrides).  At most 32. */
+ * 64 (draw, state) cells, 8 from 512, and 16 from 1024 cells with >= 20 queues; with the runtime's default of 4
+ * hardware queues: 4 groups from 1024 cells (environment EGDST_GROUPS overrides).  At most 32, and at most ndraw. */
 int egdst_set_groups(egdst_handle *h, int ngroups);
 /* History-based scheduling (on by default with more than one group): after a solve, the draws whose guess streams
  * re-based more than 1000 times (degenerate parameter draws: one such stream is ~75 ms of strictly sequential work)
