@@ -57,6 +57,7 @@ struct Batch {
     double *sM, *sC, *sV;  int *sF;    // secondary-envelope input (pieces with their extrapolation points)
     double *qM, *qC, *qV;  int *qF;    // points sorted in comp1 order
     int *rank;                          // [W] sorted position of each input point
+    int *gcls;                          // [W] class words of a stream that is sorted in global memory
     double *eM, *eV, *eC;               // [Cp] output of a secondary envelope
     double *eTH, *eIX;                  // [Cp]
     // status

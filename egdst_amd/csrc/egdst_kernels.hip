@@ -897,40 +897,104 @@ static __device__ __forceinline__ bool pt_before(double am, double av, int af, i
     return ai < bi;
 }
 
+// Rank of point i = (m, v, f) among npts points of nf functions whose lists are in comp1 order: the sum over the
+// functions of "how many of its points precede this one".  The same counts give the walk's class word of the point
+// (env_preclass): evaluated right here when cls_on.  KP: pointer type of the keys (LDS-staged or global).
+template <class KP, class ANA>
+static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KP Kv, int f, double m, double v, const eg_ldsi *fstart,
+                                                       const eg_ldsi *dims, bool cls_on, double kbound, ANA ana, int *w_out)
+{
+    int r = 0, w = 0;
+    bool force = false;
+    for (int g = 0; g < nf; g++) {
+        const int dg = dims[g];
+        if (dg <= 0) continue;
+        const int s0 = fstart[g];
+        if (g == f) {
+            r += i - s0;
+            continue;
+        }
+        // lo = points of g that precede this one.  Most lists lie entirely on one side of the point (pieces of a
+        // folded choice list overlap only near the kinks), which two or three key reads settle
+        int lo = 0;
+        if (pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) {
+            if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i))
+                lo = dg;
+            else if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i))
+                lo = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
+            else {
+                int hi = dg >= 2 ? dg - 2 : dg - 1;
+                lo = 1;
+                while (lo < hi) {  // first position in [lo, hi] that does not precede the point
+                    const int mid = (lo + hi) >> 1;
+                    if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+            }
+        }
+        r += lo;
+        if (cls_on && !force) {
+            if (lo >= dg)
+                force = true;  // g has no point ahead: cannot happen below the bound
+            else {
+                double t;
+                if (lo >= 1) {  // env_fn_cnt on the keys: the segment between g's points lo-1 and lo
+                    const double ga = Km[s0 + lo - 1], gb = Km[s0 + lo], fa = Kv[s0 + lo - 1], fb = Kv[s0 + lo];
+                    if (m == ga)
+                        t = fa;
+                    else if (m < ga || m > gb)
+                        t = -INFINITY;
+                    else
+                        t = fb * (m - ga) / (gb - ga) + fa * (gb - m) / (gb - ga);
+                } else
+                    t = ana(g, m);
+                if (v < t) w |= 1;
+                if (t < v && nf <= 29) w |= (2 << g);
+            }
+        }
+    }
+    if (cls_on) {
+        if (force || !(m < kbound))
+            w = ENV_CLS_FORCE;
+        else if (nf > 29)
+            w |= ENV_CLS_NOMASK;
+    }
+    *w_out = w;
+    return r;
+}
+
 // Sort npts points of nf functions (function f occupies [fstart[f], fstart[f]+dims[f]) of the input) into
 // (om,oc,ov,of) and record rank[].  Each function's list is normally already ordered, so the rank of a point
 // is a sum of binary searches (a merge); an unordered list falls back to counting.
+template <class ANA>
 static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const double *im, const double *ic, const double *iv, const int *ifn,
                                      const eg_ldsi *fstart, const eg_ldsi *dims, double *om, double *oc, double *ov, int *of,
-                                     int *rank, int *sh, int *oob, int *dbg)
+                                     int *rank, int *sh, int *oob, int *dbg, int *cls, int *fused, ANA ana)
 {
     int bad = 0;
     for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
         if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
     bad = blk_sum(bad, sh);
+    double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
+    *fused = 0;
+    if (!bad && cls) {
+        for (int g = 0; g < nf; g++)
+            if (dims[g] > 0) {
+                const double last = im[fstart[g] + dims[g] - 1];
+                if (last < kbound) kbound = last;
+            }
+        *fused = 1;
+    }
     for (int i = threadIdx.x; i < npts; i += ENV_BS) {
         const double m = im[i], v = iv[i];
         const int f = ifn[i];
         int r = 0;
         if (!bad) {
-            for (int g = 0; g < nf; g++) {
-                const int dg = dims[g];
-                if (dg <= 0) continue;
-                const int s = fstart[g];
-                if (g == f) {
-                    r += i - s;
-                    continue;
-                }
-                int lo = 0, hi = dg;  // first index of g that is not before (m,v,f)
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (pt_before(im[s + mid], iv[s + mid], g, s + mid, m, v, f, i))
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                r += lo;
-            }
+            int w = 0;
+            r = eg_rank_classify(i, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
+            if (cls && r >= 0 && r < npts) cls[r] = w;
         } else {
             for (int j = 0; j < npts; j++)
                 if (pt_before(im[j], iv[j], ifn[j], j, m, v, f, i)) r++;
@@ -1031,65 +1095,9 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
             const int f = ifn[i];
             int r = 0;
             if (!bad) {
-                int w = 0;          // class word of this point (env_preclass)
-                bool force = false;
-                for (int g = 0; g < nf; g++) {
-                    const int dg = dims[g];
-                    if (dg <= 0) continue;
-                    const int s0 = fstart[g];
-                    if (g == f) {
-                        r += i - s0;
-                        continue;
-                    }
-                    // lo = points of g that precede this one.  The list is in comp1 order and most lists lie entirely
-                    // on one side of the point (pieces of a folded choice list overlap only near the kinks), which
-                    // two or three key reads settle
-                    int lo = 0;
-                    if (pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) {
-                        if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i))
-                            lo = dg;
-                        else if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i))
-                            lo = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
-                        else {
-                            int hi = dg >= 2 ? dg - 2 : dg - 1;
-                            lo = 1;
-                            while (lo < hi) {  // first position in [lo, hi] that does not precede the point
-                                const int mid = (lo + hi) >> 1;
-                                if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
-                                    lo = mid + 1;
-                                else
-                                    hi = mid;
-                            }
-                        }
-                    }
-                    r += lo;
-                    if (cls && !force) {
-                        if (lo >= dg)
-                            force = true;  // g has no point ahead: cannot happen below the bound
-                        else {
-                            double t;
-                            if (lo >= 1) {  // env_fn_cnt on the staged keys: the segment between g's points lo-1 and lo
-                                const double ga = Km[s0 + lo - 1], gb = Km[s0 + lo], fa = Kv[s0 + lo - 1], fb = Kv[s0 + lo];
-                                if (m == ga)
-                                    t = fa;
-                                else if (m < ga || m > gb)
-                                    t = -INFINITY;
-                                else
-                                    t = fb * (m - ga) / (gb - ga) + fa * (gb - m) / (gb - ga);
-                            } else
-                                t = ana(g, m);
-                            if (v < t) w |= 1;
-                            if (t < v && nf <= 29) w |= (2 << g);
-                        }
-                    }
-                }
-                if (cls) {
-                    if (force || !(m < kbound))
-                        w = ENV_CLS_FORCE;
-                    else if (nf > 29)
-                        w |= ENV_CLS_NOMASK;
-                    if (r >= 0 && r < npts) cls[r] = w;
-                }
+                int w = 0;  // class word of this point
+                r = eg_rank_classify(i, nf, Km, Kv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
+                if (cls && r >= 0 && r < npts) cls[r] = w;
             } else {
                 for (int j = 0; j < npts; j++)
                     if (pt_before(Km[j], Kv[j], ifn[j], j, m, v, f, i)) r++;
@@ -1586,21 +1594,21 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             iM = pM, iC = pC, iV = pV, iF = pF;
         }
         // ---- common: sort the stream (comp1 order) and walk it ----------------------------------------
+        // value of function g before its first point (env_analytic / env_evf of the walk)
+        const int sec_id_ = job.sec_id;
+        const double sec_ev_ = job.sec_ev;
+        auto ana = [&](int g, double x) -> double {
+            const double ev = (sec_id_ >= 0) ? (g == sec_id_ ? sec_ev_ : -INFINITY) : s_evfa0[g];
+            if (ev == -INFINITY) return -INFINITY;
+            ms_pv cv;
+            cv.it = it;
+            cv.ist = ist;
+            cv.id = g;
+            cv.cash = cv.savings = cv.shock = 0;
+            return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
+        };
+        int fused = 0;
         if (job.npts <= lcap) {
-            // value of function g before its first point (env_analytic / env_evf of the walk)
-            const int sec_id_ = job.sec_id;
-            const double sec_ev_ = job.sec_ev;
-            auto ana = [&](int g, double x) -> double {
-                const double ev = (sec_id_ >= 0) ? (g == sec_id_ ? sec_ev_ : -INFINITY) : s_evfa0[g];
-                if (ev == -INFINITY) return -INFINITY;
-                ms_pv cv;
-                cv.it = it;
-                cv.ist = ist;
-                cv.id = g;
-                cv.cash = cv.savings = cv.shock = 0;
-                return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
-            };
-            int fused = 0;
             const eg_ldss *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
                                                sh, &s_oob, Lq, &fused, ana);
             STAMP(3);  // LDS sort
@@ -1620,11 +1628,13 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             }
             return;
         } else {
-            blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg);
+            int *gcls = b.gcls + wo;  // class words of the sorted stream
+            blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg, gcls, &fused,
+                          ana);
             if (s_oob) ENV_FAIL(2714);
             {
-                int we = 0, wn = 0, wm = 0;  // (sF is free once the stream is sorted: it holds the classification words)
-                run_walk<false>(&E, job, qM, qC, qV, qF, rank, sF, &we, &wn, &wm, 0);
+                int we = 0, wn = 0, wm = 0;
+                run_walk<false>(&E, job, qM, qC, qV, qF, rank, gcls, &we, &wn, &wm, fused);
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         }
