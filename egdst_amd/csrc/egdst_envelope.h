@@ -450,18 +450,28 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
 #endif
 
 // (value, index) with the larger value, ties to the smaller index; idx < 0 = absent
-static __device__ __forceinline__ void env_wave_argmax(double *v, int *idx)
+// The candidates sit on the first min(nf, wave) lanes: a butterfly over the next power of two, then a broadcast from
+// lane 0 (2 rounds for the 2 functions of a typical primary envelope instead of 6).
+static __device__ __forceinline__ int env_wave_width(int nf)
 {
-    for (int o = EG_WAVE / 2; o > 0; o >>= 1) {
+    int w = 1;
+    while (w < nf && w < EG_WAVE) w <<= 1;
+    return w;
+}
+static __device__ __forceinline__ void env_wave_argmax(double *v, int *idx, int nf)
+{
+    for (int o = env_wave_width(nf) >> 1; o > 0; o >>= 1) {
         const double ov = __shfl_xor(*v, o);
         const int oi = __shfl_xor(*idx, o);
         if (oi >= 0 && (*idx < 0 || ov > *v || (ov == *v && oi < *idx))) *v = ov, *idx = oi;
     }
+    *v = __shfl(*v, 0);
+    *idx = __shfl(*idx, 0);
 }
-static __device__ __forceinline__ int env_wave_min(int x)
+static __device__ __forceinline__ int env_wave_min(int x, int nf)
 {
-    for (int o = EG_WAVE / 2; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
-    return x;
+    for (int o = env_wave_width(nf) >> 1; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o));
+    return __shfl(x, 0);
 }
 
 // Over the functions j with dims[j] > 0, j != ex1, j != ex2 (and, with marks, mark[j] != 1):
@@ -481,12 +491,12 @@ static __device__ __forceinline__ int env_wave_pick(EnvCtxT<L> &e, double x, dou
         if (thr < t && (bj < 0 || t > bv)) bv = t, bj = j;  // ascending j: an equal value keeps the earlier index
     }
     if (first) {
-        const int j0 = env_wave_min(bj < 0 ? 0x7fffffff : bj);
+        const int j0 = env_wave_min(bj < 0 ? 0x7fffffff : bj, e.nf);
         if (j0 == 0x7fffffff) return -1;
         *val = __shfl(bv, j0 & (EG_WAVE - 1));
         return j0;
     }
-    env_wave_argmax(&bv, &bj);
+    env_wave_argmax(&bv, &bj, e.nf);
     if (bj >= 0) *val = bv;
     return bj;
 }
@@ -646,7 +656,7 @@ template <bool L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L
                 if (tj != tj) continue;
                 if (bj < 0 || tj > bv || (tj == bv && j < bj)) bv = tj, bj = j;
             }
-            env_wave_argmax(&bv, &bj);
+            env_wave_argmax(&bv, &bj, e.nf);
             if (fv != fv)
                 e.ci = f;  // every comparison with NaN is false: nothing replaces the own point
             else
