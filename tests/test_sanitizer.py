@@ -65,3 +65,14 @@ def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
     for ln in lines:
         st, where, ev, ref_rc = eval(ln.split(' ', 3)[3])
         assert st == 15 and where == (11, 0) and ref_rc != 0, ln
+
+
+def test_plain_sequential_walk_build_agrees():
+    """EGDST_SEQ_WALK builds the envelope walk as the literal one-point-at-a-time restatement of the reference loop
+    (env_step / env_crossing) instead of the wave-cooperative one; both must reproduce the oracle bit for bit."""
+    env = dict(os.environ, EMU_SANITIZE='0', EMU_SEQ_WALK='1')
+    for args in (['retirement2', 'T=8, ngridm=60'], ['occ3', 'T=6, ngridm=30, ngridmax=100']):
+        r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py')] + args, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
