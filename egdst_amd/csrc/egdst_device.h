@@ -35,6 +35,8 @@ struct Batch {
     Geom g;
     int draw0;           // first schedule slot of the group this launch works on (groups run on their own streams)
     const int *order;    // [ndraw] schedule: slot -> draw (identity until the host re-balances, egdst_host.inc)
+    struct Env1Scratch *e1sc;  // single-choice models: per (slot, state) scratch of the k_env1_* kernels
+    int *e1first, *e1cnt;      // first stopping candidate; rows per workgroup [E1 workgroups per cell]
     int *negflag;        // [(draw*MS_NST+ist)*MS_ND+id] a grid point of the stream signalled c1<=0 (set by k_grid)
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
@@ -70,6 +72,7 @@ struct Batch {
                                    // period + 24 B per row written + 16 B per threshold
 };
 
+struct Env1Scratch;
 struct ProbeOut {
     int active;       // choice is in the choice set (and the state feasible)
     int seq;          // 1: the whole stream was generated sequentially by k_fixup (candidates 0..np-1, all kept)

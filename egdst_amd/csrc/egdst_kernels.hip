@@ -1694,6 +1694,242 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-choice models (MS_ND == 1, e.g. the Deaton family): in the regular case the "envelope" of a cell is the stop
+// rule, the keep rule and the removal of repeated grid values -- a stream compaction with nothing sequential in it,
+// which one workgroup per cell (k_envelope) does at the speed of one CU (C4: 65 536 points, 0.58 ms per period, 77 %
+// of a solve).  Three small kernels spread a cell over E1_NB workgroups instead:
+//   k_env1_a  first requested point whose returned M stops the stream (atomicMin per cell);
+//   k_env1_b  per workgroup: rows it will write, evaluations, and whether anything irregular turns up (a fold, a list
+//             out of order, a hard error, a zero-consumption signal, an empty list, a regenerated stream);
+//   k_env1_c  prefix over the workgroups' counts, rows written in place; cells flagged irregular are left untouched
+//             and handed to k_envelope (pass 1), which then behaves exactly as it always did.
+#if MS_ND == 1
+#define E1_BS 256
+struct Env1Scratch {  // per schedule slot and state, zeroed by the host before pass a (e1first: set to a large value)
+    int flags, n2;
+    unsigned long long evals;
+};
+#define E1_IRREGULAR 1
+static __device__ __forceinline__ bool e1_kept(const Batch &b, const ProbeOut &P, size_t co, int n, int terminal)
+{
+    if (terminal) return true;
+    if (n == 0) return P.np != 0;
+    return b.cSt[co + n] == 0 && isfinite(b.cM[co + n]);
+}
+// candidate range [lo, hi) of workgroup blk of nb, for requested candidates 0..nreq
+static __device__ __forceinline__ void e1_range(int nreq, int blk, int nb, int *lo, int *hi)
+{
+    const int per = (nreq + 1 + nb - 1) / nb;
+    *lo = blk * per;
+    *hi = min(nreq + 1, *lo + per);
+}
+static __device__ __forceinline__ int e1_nreq(const Batch &b, const ProbeOut &P, int first, int terminal)
+{
+    if (terminal) return b.g.ngridm - 1;
+    const int navail = P.grid ? min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls) : 0;
+    return min(first, navail);
+}
+
+__global__ void __launch_bounds__(E1_BS) k_env1_a(Batch b, int it, int terminal, int *e1first, int nb)
+{
+    const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
+    int *F = e1first + ((size_t)b.draw0 * MS_NST + cellslot);
+    if (b.status[draw] || terminal) return;
+    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND];
+    if (!P.active || P.seq || !P.grid) return;
+    const size_t co = eg_cand(b, draw, ist, 0);
+    const int navail = min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls);
+    int lo, hi;
+    e1_range(navail, blockIdx.x, nb, &lo, &hi);
+    int first = 0x7fffffff;
+    for (int n = max(lo, 1) + (int)threadIdx.x; n < hi; n += E1_BS)
+        if (!(b.cR[co + n] < b.g.mmax)) {
+            first = n;
+            break;
+        }
+    for (int o = WAVE / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && first != 0x7fffffff) atomicMin(F, first);
+}
+
+// rows written by candidates [lo, hi) of a cell: kept, and not a repeat of the previous kept grid value; flags folds etc.
+static __device__ __forceinline__ int e1_count(const Batch &b, const ProbeOut &P, size_t co, int lo, int hi, int terminal, int *flags,
+                                               int *n2, unsigned long long *ev, int write, double *oM, double *oC, double *oV, int d0)
+{
+    // every thread takes a contiguous chunk; the predecessor of its first kept point is found by scanning back
+    const int per = (hi - lo + E1_BS - 1) / E1_BS;
+    const int a = lo + (int)threadIdx.x * per, z = min(hi, a + per);
+    int cnt = 0;
+    bool have = false;
+    double pm = 0, pv = 0;
+    for (int n = a; n < z; n++) {
+        if (!write && n >= 1 && !terminal) {
+            const int st = b.cSt[co + n];
+            if (st < 0 || st == 1) *flags |= E1_IRREGULAR;  // hard error / c1<=0 left over: k_envelope reports it
+            if (st == 2) *n2 += 1;
+            *ev += (unsigned long long)b.cCnt[co + n];
+        }
+        if (!e1_kept(b, P, co, n, terminal)) continue;
+        const double m = b.cM[co + n], v = b.cV[co + n];
+        if (!have) {  // previous kept candidate of the cell, if any
+            for (int q = n - 1; q >= 0 && !have; q--)
+                if (e1_kept(b, P, co, q, terminal)) pm = b.cM[co + q], pv = b.cV[co + q], have = true;
+            if (!have) {  // first kept point of the cell
+                if (write) oM[d0 + cnt] = m, oC[d0 + cnt] = b.cC[co + n], oV[d0 + cnt] = v;
+                cnt++;
+                pm = m, pv = v, have = true;
+                continue;
+            }
+        }
+        if (!write) {
+            if (!terminal && (pm > m || pv > v)) *flags |= E1_IRREGULAR;           // the list folds back: secondary envelope
+            if (pm > m || (pm == m && pv < v)) *flags |= E1_IRREGULAR;             // not in comp1 order: general sort
+        }
+        if (m != pm) {
+            if (write) oM[d0 + cnt] = m, oC[d0 + cnt] = b.cC[co + n], oV[d0 + cnt] = v;
+            cnt++;
+        }
+        pm = m, pv = v;
+    }
+    return cnt;
+}
+
+// exclusive scan of one int per thread over the workgroup; *total = sum
+static __device__ __forceinline__ int e1_scan(int v, int *sh, int *total)
+{
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < E1_BS; o <<= 1) {
+        const int t = (tid >= o) ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    *total = sh[E1_BS - 1];
+    const int ex = sh[tid] - v;
+    __syncthreads();
+    return ex;
+}
+
+__global__ void __launch_bounds__(E1_BS) k_env1_b(Batch b, int it, int terminal, Env1Scratch *sc, const int *e1first, int *blkcnt, int nb,
+                                                  int defer_all /* tests: treat every cell as irregular */)
+{
+    __shared__ int sh[E1_BS];
+    const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
+    const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
+    Env1Scratch *S = sc + sslot;
+    if (b.status[draw]) return;
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it, cur.ist = ist, cur.id = 0, cur.cash = cur.savings = cur.shock = 0;
+    if (ms_feasible(&E, &cur) != 1) return;  // (k_env1_c writes the empty cell)
+    const ProbeOut P = b.probe[cell * MS_ND];
+    if (!P.active || P.seq || defer_all) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S->flags, E1_IRREGULAR);
+        return;
+    }
+    const size_t co = eg_cand(b, draw, ist, 0);
+    const int nreq = e1_nreq(b, P, e1first[sslot], terminal);
+    int lo, hi;
+    e1_range(nreq, blockIdx.x, nb, &lo, &hi);
+    int flags = 0, n2 = 0;
+    unsigned long long ev = 0;
+    const int cnt = e1_count(b, P, co, lo, hi, terminal, &flags, &n2, &ev, 0, nullptr, nullptr, nullptr, 0);
+    int total;
+    (void)e1_scan(cnt, sh, &total);
+    if (threadIdx.x == 0) blkcnt[sslot * nb + blockIdx.x] = total;
+    if (flags) atomicOr(&S->flags, flags);
+    if (n2) atomicAdd(&S->n2, n2);
+    if (ev) atomicAdd(&S->evals, ev);
+}
+
+__global__ void __launch_bounds__(E1_BS) k_env1_c(Batch b, int it, int terminal, Env1Scratch *sc, const int *e1first, const int *blkcnt, int nb)
+{
+    __shared__ int sh[E1_BS];
+    const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
+    const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int slot = (b.g.nslots == 2) ? (it & 1) : it;
+    const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    Env1Scratch *S = sc + sslot;
+    if (b.status[draw]) {
+        if (blk == 0 && tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        return;
+    }
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it, cur.ist = ist, cur.id = 0, cur.cash = cur.savings = cur.shock = 0;
+    if (ms_feasible(&E, &cur) != 1) {
+        if (blk == 0 && tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        return;
+    }
+    int outn = 0, before = 0;
+    for (int k = 0; k < nb; k++) {
+        const int c = blkcnt[sslot * nb + k];
+        if (k < blk) before += c;
+        outn += c;
+    }
+    // anything k_envelope would treat differently goes to k_envelope: irregular lists, no point at all (error 15), a
+    // full grid (error 13), no room for the threshold (error 20), the compact capacity
+    if ((S->flags & E1_IRREGULAR) || outn == 0 || outn >= b.g.ngridmax || outn > b.g.Cp || 1 >= b.g.nthrhmax) {
+        if (blk == 0 && tid == 0) b.defer[cell] = 1;
+        return;
+    }
+    const ProbeOut P = b.probe[cell * MS_ND];
+    const size_t co = eg_cand(b, draw, ist, 0);
+    const int nreq = e1_nreq(b, P, e1first[sslot], terminal);
+    int lo, hi;
+    e1_range(nreq, blk, nb, &lo, &hi);
+    double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
+    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
+    // rows of this workgroup: count per thread once more (cheap), scan, then write in place
+    int fl = 0, n2_ = 0;
+    unsigned long long ev_ = 0;
+    const int cnt = e1_count(b, P, co, lo, hi, terminal, &fl, &n2_, &ev_, 0, nullptr, nullptr, nullptr, 0);
+    int total;
+    const int ex = e1_scan(cnt, sh, &total);
+    (void)e1_count(b, P, co, lo, hi, terminal, &fl, &n2_, &ev_, 1, oM, oC, oV, 1 + before + ex);
+    // rows past the new end of the table are zero (see k_envelope); every workgroup clears a slice
+    const int hw_rows = b.thw[tk], hw_th = b.thhw[tk];
+    for (int i = outn + 1 + blk * E1_BS + tid; i < hw_rows; i += nb * E1_BS) oM[i] = oC[i] = oV[i] = 0.0;
+    if (blk == 0) {
+        for (int i = 1 + tid; i < hw_th; i += E1_BS) oTH[i] = oD[i] = 0.0;
+        if (tid == 0) {
+            oTH[0] = b.g.a0;
+            oD[0] = 0;
+            oM[0] = b.g.a0;
+            oC[0] = 0;
+            oV[0] = (S->n2 > 0) ? -INFINITY : P.evfa0;
+            b.tlen[tk] = outn + 1;
+            b.tthlen[tk] = 1;
+            const unsigned long long evals = S->evals + (terminal ? 0ull : (unsigned long long)P.probe_evals);
+            if (evals) atomicAdd(&b.evals[draw], evals);
+            unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull;
+            if (!terminal) {
+                const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+                const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
+                by += 24ull * (unsigned long long)b.tlen[k1] + 16ull * (unsigned long long)b.tthlen[k1];
+            }
+            atomicAdd(&b.algbytes[draw], by);
+        }
+    }
+}
+
+// the high-water marks of the cells the fast path completed (after k_env1_c: every workgroup has read the old marks)
+__global__ void k_env1_d(Batch b, int it, int ncells)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncells) return;
+    const int ist = k % MS_NST, draw = b.order[b.draw0 + k / MS_NST];
+    const size_t cell = (size_t)draw * MS_NST + ist;
+    const int slot = (b.g.nslots == 2) ? (it & 1) : it;
+    const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    if (b.defer[cell] || b.status[draw]) return;
+    if (b.tlen[tk] > 0) b.thw[tk] = b.tlen[tk], b.thhw[tk] = 1;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // Forward simulation, one lane per agent (egdst_simulator.c:204-383, policy :145-199, output :122-143).
 struct SimArgs {
     int draw, nsim, rndtype, nout;

@@ -112,19 +112,17 @@ static inline void __threadfence_block() { __sync_synchronize(); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
-static inline int atomicCAS(int *p, int cmp, int val)
-{
-    int old = *p;
-    if (old == cmp) *p = val;
-    return old;
-}
+static inline int atomicCAS(int *p, int cmp, int val) { return __sync_val_compare_and_swap(p, cmp, val); }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __sync_fetch_and_add(p, v); }
-static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
+static inline int atomicAdd(int *p, int v) { return __sync_fetch_and_add(p, v); }
+static inline int atomicOr(int *p, int v) { return __sync_fetch_and_or(p, v); }
+static inline int atomicMin(int *p, int v)
 {
-    unsigned long long old = *p;
-    *p += v;
-    return old;
+    int o = *p;
+    while (v < o && !__sync_bool_compare_and_swap(p, o, v)) o = *p;
+    return o;
 }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __sync_fetch_and_add(p, v); }
 
 typedef int hipError_t;
 typedef void *hipStream_t;

@@ -76,3 +76,20 @@ def test_plain_sequential_walk_build_agrees():
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('mode', ['fast', 'defer_all', 'off'])
+def test_single_choice_envelope_kernels(mode):
+    """Single-choice models compact a cell with many workgroups (k_env1_*); irregular cells are handed to k_envelope.
+    The fast path, the hand-over (forced for every cell) and the general kernel alone must all equal the oracle."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
+    if mode == 'defer_all':
+        env['EGDST_E1_DEFER_ALL'] = '1'
+    if mode == 'off':
+        env['EGDST_NO_ENV1'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py'), 'deaton2', ''], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout and 'evals=24474/24474' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
