@@ -2035,6 +2035,93 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
     if (terr) atomicCAS(a.err, 0, EGDST_E_TRPR_CASES);
 }
 
+// ---------------------------------------------------------------------------------------------
+// egdst_call.c:17-164, the accessor behind egdstmodel.call: one lane per row of arguments.  The host has already found
+// the first row whose index arguments are out of range (`first_bad`; rows from there on are NaN, egdst_host.inc), so the
+// rows are independent.  sw: 1 utility, 2 marginal utility, 3 discount, 4 budget, 5 marginal budget, 6 value function.
+struct CallArgs {
+    int draw, sw, narg, ncol, first_bad, bad_keeps_zero;
+    const double *args;  // [narg x ncol] column-major
+    double *res;         // [narg]
+};
+
+__global__ void __launch_bounds__(GRID_BS) k_call(Batch b, CallArgs a)
+{
+    const int i = blockIdx.x * GRID_BS + threadIdx.x;
+    if (i >= a.narg) return;
+    if (i >= a.first_bad) {
+        a.res[i] = (i == a.first_bad && a.bad_keeps_zero) ? 0.0 : NAN;
+        return;
+    }
+    const int nt = b.g.nt, draw = a.draw;
+    const size_t n = (size_t)a.narg;
+    const double *arg = a.args + i;
+    ms_env E = eg_env(b, draw);
+    ms_pv cur, nxt;
+    cur.it = (int)arg[0] - b.g.t0;
+    cur.ist = (int)arg[n] - 1;
+    cur.id = (a.ncol > 2 && a.sw != 6) ? (int)arg[2 * n] - 1 : 0;
+    cur.cash = cur.savings = cur.shock = 0;
+    nxt = cur;
+    double r = 0.0;
+    switch (a.sw) {
+    case 1:
+    case 2:
+        if (arg[3 * n] > b.g.mmax - b.g.a0)
+            r = NAN;
+        else
+            r = a.sw == 1 ? ms_utility(&E, &cur, arg[3 * n]) : ms_utility_marginal(&E, &cur, arg[3 * n]);
+        break;
+    case 3:
+        r = ms_discount(&E, &cur);
+        break;
+    case 4:
+    case 5:
+        nxt.it = cur.it + 1;
+        nxt.id = 0;
+        nxt.savings = arg[3 * n];
+        nxt.ist = (int)arg[4 * n] - 1;
+        nxt.shock = arg[5 * n];
+        if (nxt.it < 0 || nxt.it > nt - 1 || nxt.savings < b.g.a0)
+            r = NAN;
+        else
+            r = a.sw == 4 ? ms_cashinhand(&E, &cur, &nxt) : ms_cashinhand_marginal(&E, &cur, &nxt);
+        break;
+    case 6:
+        cur.cash = arg[2 * n];
+        if (cur.cash > b.g.mmax)
+            r = NAN;
+        else if (cur.it == nt - 1)
+            r = ms_utility(&E, &cur, MS_MAX(0, cur.cash));
+        else {
+            const Tab t = eg_tab(b, cur.it, draw, cur.ist);  // (history kept: slot = period)
+            if (t.len <= 0)
+                r = NAN;  // "Solution missing for given it,ist.."
+            else if (t.len < 2)
+                r = -1.0;  // linter's error return (egdst_lib.c:166)
+            else {
+                const double ma0 = t.M[1], evf = t.V[0];
+                int k = eg_bracket(cur.cash, t.M, t.len, 0);
+                const double c = eg_lerp(cur.cash, t.M[k], t.M[k + 1], t.C[k], t.C[k + 1]);
+                cur.savings = cur.cash - c;
+                int ith = 0;
+                while (ith < t.thlen && cur.cash >= t.TH[ith]) ith++;
+                cur.id = (int)t.D[ith > 0 ? ith - 1 : 0];
+                if (cur.cash < ma0 && evf > -INFINITY)
+                    r = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+                else if (cur.cash < ma0 && evf == -INFINITY)
+                    r = -INFINITY;
+                else
+                    r = eg_lerp(cur.cash, t.M[k], t.M[k + 1], t.V[k], t.V[k + 1]);
+            }
+        }
+        break;
+    default:
+        r = NAN;
+    }
+    a.res[i] = r;
+}
+
 __global__ void k_fill_nan(double *p, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -620,6 +620,21 @@ class egdstmodel:  # noqa: N801  (reference class name)
         self.sims = sims
         return sims
 
+    CALL_NAMES = {'utility': 1, 'util': 1, 'u': 1, 'mutility': 2, 'mu': 2, 'discount': 3, 'df': 3, 'budget': 4, 'b': 4,
+                  'mbudget': 5, 'mb': 5, 'value': 6, 'vf': 6}
+
+    def call(self, func, funcargs):
+        """``res=model.call(funcname,funcargs)`` (egdstmodel.m:1181-1207 -> egdst_call.c): runs internal functions of the
+        solved model -- 'utility'|'util'|'u' (it,ist,id,consumption), 'mutility'|'mu', 'discount'|'df' (it,ist),
+        'budget'|'b' (it,ist,id,savings,ist(t+1),shock), 'mbudget'|'mb', 'value'|'vf' (it,ist,cash); rows of funcargs
+        are evaluated independently (vector input)."""
+        if self.needtocompile or self.M is None:
+            raise EgdstError('The model needs to be compiled and solved first!\nRun <model>.compile')
+        if func not in self.CALL_NAMES:
+            raise EgdstError('Unknown internal model function to call!')
+        from . import runtime
+        return runtime.call_model(self, self.CALL_NAMES[func], funcargs)
+
     def sims2panel(self):
         # egdstmodel.m:1279-1292
         if self.sims is None:

@@ -31,7 +31,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work']
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -66,6 +66,7 @@ class ModelLibrary:
                                            C.POINTER(C.c_void_p)]
         L.egdst_set_groups.argtypes = [C.c_void_p, C.c_int]
         L.egdst_set_adaptive.argtypes = [C.c_void_p, C.c_int]
+        L.egdst_call.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.egdst_get_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_objective.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -341,6 +342,17 @@ class Solver:
             self.lib.check(self.lib.lib.egdst_get_cell_D(self.h, draw, it, ist, _dp(out)))
         return np.ascontiguousarray(out.T)
 
+    def call(self, sw, args, draw=0):
+        """egdst_call gateway (egdst_call.c:17-164): sw 1 utility, 2 marginal utility, 3 discount, 4 budget, 5 marginal
+        budget, 6 value function; args [narg x ncol] with 1-based it/ist/id as in MATLAB.  Returns [narg]."""
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.call(sw, args, j_)
+        a = np.asfortranarray(np.atleast_2d(np.asarray(args, dtype=np.float64)))
+        res = np.zeros(a.shape[0])
+        self.lib.check(self.lib.lib.egdst_call(self.h, draw, int(sw), a.shape[0], a.shape[1], _dp(a), _dp(res)))
+        return res
+
     def simulate(self, init, randstream, rndtype=0, draw=0):
         if len(self._redo) and self._route(draw)[0] is not self:
             s_, j_ = self._route(draw)
@@ -371,6 +383,13 @@ def solve_model(model):
         import warnings
         warnings.warn(sol.err)
     return sol
+
+
+def call_model(model, sw, args):
+    s = model.__dict__.get('_solver')
+    if s is None:
+        raise EgdstRuntimeError(40, 'Error: the model has not yet been solved!')
+    return s.call(sw, args, draw=0)
 
 
 def simulate_model(model, rndtype):

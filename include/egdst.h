@@ -146,6 +146,14 @@ int egdst_get_solution(egdst_handle *h, int draw, int *lens, int *thlens, double
 int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
                    long long nrand, int rndtype, double *sims);
 
+/* Model-function accessor behind egdstmodel.call (egdst_call.c:17-164; egdstmodel.m:1181-1207).  sw: 1 utility
+ * (it, ist, id, consumption), 2 marginal utility (same), 3 discount (it, ist), 4 budget (it, ist, id, savings, ist1,
+ * shock), 5 marginal budget (same), 6 value function from the solved tables (it, ist, cash).  args: host, [narg x ncol]
+ * column-major with MATLAB's 1-based it/ist/id; res: host, [narg].  The gateway's conventions are kept: the first row
+ * with an out-of-range index makes that row and every later one NaN, a wrong column count leaves zeros.  Requires
+ * keep_history=1 (the value function reads the period's table). */
+int egdst_call(egdst_handle *h, int draw, int sw, int narg, int ncol, const double *args, double *res);
+
 /* Objective contributions of an estimation loop (new surface): out_dev[2*draw+{0,1}] =
  * value and consumption at the first endogenous grid point of (it=0, ist=0); NaN for failed draws.  The buffer
  * is device memory (e.g. a torch tensor) so that the cross-GPU reduce (RCCL) needs no host copy.  Enqueued on

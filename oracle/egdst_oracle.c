@@ -1089,3 +1089,101 @@ void egdst_oracle_info(int *out)
     out[4] = MS_NPARAM;
     out[5] = MS_NEQ;
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* egdst_call.c:17-164 -- model-function accessor behind egdstmodel.call (egdstmodel.m:1181-1207):
+ *   sw 1 utility(it,ist,id,c)  2 marginal utility  3 discount(it,ist)  4 budget(it,ist,id,savings,ist1,shock)
+ *   5 marginal budget  6 value function(it,ist,cash) from the solved tables (vf(), :127-164).
+ * args: [narg x ncol] column-major, 1-based it/ist/id as in MATLAB; res[narg] starts as zeros (mxCreateDoubleMatrix).
+ * Kept from the reference: an out-of-range it/ist/id sets the switch to -1 for the rest of the call (that row and all
+ * later rows are NaN); a wrong column count returns at the first row, leaving zeros; a bad ist1 leaves its own row
+ * zero.  Differences where the reference reads past an array or an uninitialised variable: ist, id, ist1 equal to
+ * nst+1 / nd+1 pass its `>` checks (:52,56,97) -- rejected here; `value` at the terminal period uses curr.id without
+ * setting it (:121) -- id 1 here; a cash value below the first threshold indexes D[-1] (:152) -- D[0] here. */
+int egdst_oracle_call(const orc_desc *d, const double *par, const orc_solution *sol, int sw, int narg, int ncol,
+                      const double *args, double *res)
+{
+    ms_env E;
+    int i, nt = d->T - d->t0 + 1, stride = d->ngridmax + 1;
+    E.t0 = d->t0, E.T = d->T, E.ngridm = d->ngridm, E.ngridmax = d->ngridmax, E.nthrhmax = d->nthrhmax, E.ny = d->ny;
+    E.mmax = d->mmax, E.a0 = d->a0, E.par = par;
+    for (i = 0; i < narg; i++) res[i] = 0.0;
+    for (i = 0; i < narg; i++) {
+        const double *arg = args + i;
+        ms_pv cur, nxt;
+        memset(&cur, 0, sizeof cur);
+        memset(&nxt, 0, sizeof nxt);
+        cur.it = (int)arg[0 * (size_t)narg] - d->t0;
+        if (cur.it < 0 || cur.it > nt - 1) sw = -1;
+        cur.ist = (ncol > 1) ? (int)arg[1 * (size_t)narg] - 1 : -1;
+        if (cur.ist < 0 || cur.ist >= MS_NST) sw = -1;
+        if (ncol > 2 && sw != 6) {
+            cur.id = (int)arg[2 * (size_t)narg] - 1;
+            if (cur.id < 0 || cur.id >= MS_ND) sw = -1;
+        }
+        switch (sw) {
+        case 1:
+        case 2:
+            if (ncol != 4) return 0;
+            if (arg[3 * (size_t)narg] > d->mmax - d->a0)
+                res[i] = NAN;
+            else
+                res[i] = sw == 1 ? ms_utility(&E, &cur, arg[3 * (size_t)narg]) : ms_utility_marginal(&E, &cur, arg[3 * (size_t)narg]);
+            break;
+        case 3:
+            if (ncol != 2) return 0;
+            res[i] = ms_discount(&E, &cur);
+            break;
+        case 4:
+        case 5:
+            if (ncol != 6) return 0;
+            nxt.it = cur.it + 1;
+            nxt.savings = arg[3 * (size_t)narg];
+            nxt.ist = (int)arg[4 * (size_t)narg] - 1;
+            nxt.shock = arg[5 * (size_t)narg];
+            if (nxt.it < 0 || nxt.it > nt - 1)
+                res[i] = NAN;
+            else if (nxt.savings < d->a0)
+                res[i] = NAN;
+            else if (nxt.ist < 0 || nxt.ist >= MS_NST)
+                sw = -1; /* (this row keeps its zero) */
+            else
+                res[i] = sw == 4 ? ms_cashinhand(&E, &cur, &nxt) : ms_cashinhand_marginal(&E, &cur, &nxt);
+            break;
+        case 6:
+            if (ncol != 3) return 0;
+            cur.cash = arg[2 * (size_t)narg];
+            if (cur.cash > d->mmax)
+                res[i] = NAN;
+            else if (cur.it == nt - 1)
+                res[i] = ms_utility(&E, &cur, MS_MAX(0, cur.cash));
+            else {
+                size_t sl = (size_t)cur.it * MS_NST + cur.ist;
+                int nm = sol->len[sl], nth = sol->thlen[sl], ith = 0;
+                const double *gm = sol->M + sl * stride, *gc = sol->C + sl * stride, *gv = sol->V + sl * stride;
+                const double *th = sol->TH + sl * d->nthrhmax, *dd = sol->D + sl * d->nthrhmax;
+                if (nm <= 0)
+                    res[i] = NAN; /* "Solution missing for given it,ist.." */
+                else if (nm < 2)
+                    res[i] = -1.0; /* linter's error return (egdst_lib.c:166) */
+                else {
+                    double ma0 = gm[1], evf = gv[0], c = interp_lin(cur.cash, nm, gm, gc);
+                    cur.savings = cur.cash - c;
+                    while (ith < nth && cur.cash >= th[ith]) ith++;
+                    cur.id = (int)dd[ith > 0 ? ith - 1 : 0];
+                    if (cur.cash < ma0 && evf > -INFINITY)
+                        res[i] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+                    else if (cur.cash < ma0 && evf == -INFINITY)
+                        res[i] = -INFINITY;
+                    else
+                        res[i] = interp_lin(cur.cash, nm, gm, gv);
+                }
+            }
+            break;
+        default:
+            res[i] = NAN;
+        }
+    }
+    return 0;
+}

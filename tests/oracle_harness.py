@@ -97,6 +97,20 @@ class Oracle:
         sol.rc = rc
         return sol
 
+    def call(self, sol, sw, args, params=None):
+        desc, d = self._desc()
+        a = np.asfortranarray(np.atleast_2d(np.asarray(args, dtype=np.float64)))
+        res = np.zeros(a.shape[0])
+        par = np.ascontiguousarray(self.model.param_vector() if params is None else params, dtype=np.float64)
+        cs = OrcSolution(_dp(sol.M), _dp(sol.C), _dp(sol.V), _dp(sol.D), _dp(sol.TH),
+                         sol.len.ctypes.data_as(C.POINTER(C.c_int)), sol.thlen.ctypes.data_as(C.POINTER(C.c_int)))
+        self.lib.egdst_oracle_call.restype = C.c_int
+        rc = self.lib.egdst_oracle_call(C.byref(desc), _dp(par), C.byref(cs), C.c_int(int(sw)), C.c_int(a.shape[0]),
+                                        C.c_int(a.shape[1]), _dp(a), _dp(res))
+        if rc != 0:
+            raise RuntimeError('oracle call failed rc=%d' % rc)
+        return res
+
     def sim(self, sol, init, randstream, rndtype=0, params=None):
         desc, d = self._desc()
         nt = d['T'] - d['t0'] + 1

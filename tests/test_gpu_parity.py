@@ -272,3 +272,31 @@ def test_threshold_capacity_error_matches_the_reference(nthrhmax):
     assert sol.err.strip() == ref.err.strip()
     ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
     assert ok, rep
+
+
+@pytest.mark.parametrize('name', ['retirement2', 'occ3', 'retire8'])
+def test_model_function_accessor_matches_the_oracle(name):
+    """model.call / egdst_call (egdst_call.c:17-164): utility, marginal utility, discount, budget, marginal budget and
+    the value function of the solved tables, with vector input, out-of-domain values and bad indices."""
+    from call_cases import call_cases
+    m = {'retirement2': lambda: examples.retirement2(), 'occ3': lambda: examples.occ3(),
+         'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5)}[name]()
+    s = gpu_solve(m)
+    orc = Oracle(m)
+    ref = orc.solve()
+    for sw, args in call_cases(m, s.nt, s.lib.info.nst, s.lib.info.nd):
+        assert np.array_equal(s.call(sw, args), orc.call(ref, sw, args), equal_nan=True), sw
+
+
+def test_class_surface_call():
+    m = examples.retirement2()
+    m.compile()
+    m.solve()
+    ref = Oracle(m)
+    rsol = ref.solve()
+    args = [[m.t0 + 3, 1, 2.5], [m.t0 + 3, 1, 7.0]]
+    assert np.array_equal(m.call('vf', args), ref.call(rsol, 6, args))
+    assert np.array_equal(m.call('u', [[m.t0, 1, 2, 1.5]]), ref.call(rsol, 1, [[m.t0, 1, 2, 1.5]]))
+    from egdst_amd import EgdstError
+    with pytest.raises(EgdstError):
+        m.call('nonsense', args)

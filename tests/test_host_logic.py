@@ -97,3 +97,16 @@ def test_nonseparable_utility_is_rejected():
     m.u = ('utility', 'log(consumption)*(1+duw*(id==0))')
     with pytest.raises(codegen.CodegenError):
         codegen.analyse_optim(m)
+
+
+def test_call_needs_a_solved_model_and_known_names():
+    """egdstmodel.m:1181-1207: call() refuses an unsolved model and unknown function names; the aliases map to the
+    switch numbers of egdst_call.c."""
+    from egdst_amd import examples, EgdstError
+    from egdst_amd.model import egdstmodel
+    m = examples.retirement2()
+    with pytest.raises(EgdstError):
+        m.call('utility', [[1, 1, 1, 1.0]])
+    assert egdstmodel.CALL_NAMES['u'] == egdstmodel.CALL_NAMES['utility'] == 1
+    assert egdstmodel.CALL_NAMES['mu'] == 2 and egdstmodel.CALL_NAMES['df'] == 3
+    assert egdstmodel.CALL_NAMES['b'] == 4 and egdstmodel.CALL_NAMES['mb'] == 5 and egdstmodel.CALL_NAMES['vf'] == 6

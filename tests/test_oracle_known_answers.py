@@ -69,3 +69,22 @@ def test_known_answers(solved):
     if ka.get('M_nondecreasing'):
         for it in range(sol.nt):
             assert np.all(np.diff(sol.M[it, 0, :sol.len[it, 0]]) >= 0)
+
+
+def test_accessor_value_function_reproduces_the_tables():
+    """egdst_call.c vf(): at the endogenous grid points of a solved period the value function is the table's V column,
+    and below M(a0) it is the analytic u(c)+beta*evf; the bad-index and column-count rules of the gateway hold."""
+    import numpy as np
+    from egdst_amd import examples
+    from oracle_harness import Oracle
+    m = examples.retirement2()
+    o = Oracle(m, native_math=True)
+    sol = o.solve()
+    it = 5
+    n = sol.len[it, 0]
+    Mg, Vg = sol.M[it, 0, 1:n], sol.V[it, 0, 1:n]
+    v = o.call(sol, 6, np.column_stack([np.full(n - 1, it + m.t0), np.ones(n - 1), Mg]))
+    assert np.allclose(v, Vg, rtol=1e-13, atol=0)
+    r = o.call(sol, 1, [[m.t0 + 1, 1, 1, 2.0], [m.t0 + 1, 9, 1, 2.0], [m.t0 + 1, 1, 1, 2.0]])
+    assert np.isfinite(r[0]) and np.isnan(r[1]) and np.isnan(r[2])      # a bad ist poisons the rest of the call
+    assert np.array_equal(o.call(sol, 3, [[m.t0 + 1, 1, 1]]), [0.0])    # wrong column count: zeros

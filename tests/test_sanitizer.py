@@ -93,3 +93,16 @@ def test_single_choice_envelope_kernels(mode):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout and 'evals=24474/24474' in r.stdout, r.stdout + r.stderr[-2000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('args', [['retirement2', 'T=8, ngridm=60'], ['retirement8', 'T=5, ngridm=30, ny=3']])
+def test_model_function_accessor(args):
+    """egdst_call (egdstmodel.call): every switch, vector input, out-of-domain values and the gateway's bad-index rules
+    -- device code under ASan equals the oracle's restatement of egdst_call.c bit for bit."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_call.py')] + args, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'call mismatches: 0' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
