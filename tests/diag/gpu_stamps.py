@@ -12,5 +12,5 @@ for draw in [int(a) for a in sys.argv[1:]] or (0, 1):
     s.solve()
     buf = s.debug(0).view(np.uint64)
     nb, ns = int(buf[3]) >> 32, int(buf[3]) & 0xffffffff
-    print('draw', draw, '2 solves: preclass %.0f us |' % (buf[1] * 1e-2), 'stop+compact %.0f us, sort %.0f us, walk %.0f us | inside walks: %d batches %.0f us (%.2f us each), %d generic steps %.0f us (%.2f us each)' % (
+    print('draw', draw, '2 solves: separate classification pass %.0f us |' % (buf[1] * 1e-2), 'stop+compact %.0f us, sort %.0f us, walk %.0f us | inside walks: %d batches %.0f us (%.2f us each), %d generic steps %.0f us (%.2f us each)' % (
         buf[2] * 1e-2, buf[5] * 1e-2, buf[6] * 1e-2, nb, buf[7] * 1e-2, buf[7] * 1e-2 / max(nb, 1), ns, buf[4] * 1e-2, buf[4] * 1e-2 / max(ns, 1)))
