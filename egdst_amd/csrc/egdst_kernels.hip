@@ -2122,6 +2122,38 @@ __global__ void __launch_bounds__(GRID_BS) k_call(Batch b, CallArgs a)
     a.res[i] = r;
 }
 
+// Mean of one (column, period) cell of the simulated paths over the agents that have a value there (the others are NaN:
+// died, or started outside the admissible range).  One workgroup per cell; each thread adds its agents in index order,
+// then a fixed tree over the threads: the result does not depend on scheduling.
+#ifdef EGDST_EMU
+#define MOM_BS 1
+#else
+#define MOM_BS 256
+#endif
+__global__ void __launch_bounds__(MOM_BS) k_moments(const double *sims, int nsim, int ncell, double *means, int *counts)
+{
+    __shared__ double ssum[MOM_BS];
+    __shared__ int scnt[MOM_BS];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    double acc = 0;
+    int cnt = 0;
+    for (int i = tid; i < nsim; i += MOM_BS) {
+        const double v = sims[(size_t)cell + (size_t)ncell * i];
+        if (v == v) acc += v, cnt++;
+    }
+    ssum[tid] = acc;
+    scnt[tid] = cnt;
+    __syncthreads();
+    for (int o = MOM_BS / 2; o > 0; o >>= 1) {
+        if (tid < o) ssum[tid] += ssum[tid + o], scnt[tid] += scnt[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[cell] = scnt[0];
+        means[cell] = scnt[0] ? ssum[0] / scnt[0] : NAN;
+    }
+}
+
 __global__ void k_fill_nan(double *p, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

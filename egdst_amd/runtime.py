@@ -31,7 +31,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call']
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -86,6 +86,8 @@ class ModelLibrary:
             [C.POINTER(C.c_double)] * 5
         L.egdst_simulate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
                                      C.c_longlong, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_simulate_moments.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
+                                             C.c_longlong, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.egdst_get_debug.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.egdst_objective_dev.argtypes = [C.c_void_p, C.c_void_p]
         L.egdst_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -341,6 +343,22 @@ class Solver:
         if nth.value:
             self.lib.check(self.lib.lib.egdst_get_cell_D(self.h, draw, it, ist, _dp(out)))
         return np.ascontiguousarray(out.T)
+
+    def simulate_moments(self, init, randstream, rndtype=0, draw=0):
+        """(means [nt, nout], counts [nt, nout]) of the simulated paths over the agents that have a value in a period;
+        the paths themselves stay on the device (egdst_simulate_moments)."""
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.simulate_moments(init, randstream, rndtype, j_)
+        init = np.asfortranarray(np.atleast_2d(np.asarray(init, dtype=np.float64)))
+        info = self.lib.info
+        nout = 11 + info.nnst + info.nnd + info.neq
+        means = np.zeros((self.nt, nout))
+        counts = np.zeros((self.nt, nout), dtype=np.int32)
+        rs = np.ascontiguousarray(randstream, dtype=np.float64)
+        self.lib.check(self.lib.lib.egdst_simulate_moments(self.h, draw, _dp(init), init.shape[0], _dp(rs), rs.size, int(rndtype),
+                                                           _dp(means), _ip(counts)))
+        return means, counts
 
     def call(self, sw, args, draw=0):
         """egdst_call gateway (egdst_call.c:17-164): sw 1 utility, 2 marginal utility, 3 discount, 4 budget, 5 marginal

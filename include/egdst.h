@@ -146,6 +146,12 @@ int egdst_get_solution(egdst_handle *h, int draw, int *lens, int *thlens, double
 int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
                    long long nrand, int rndtype, double *sims);
 
+/* Simulated moments (new surface): the same simulation, but only the per-period means of the
+ * simulated columns leave the device -- means[col + nout*it] over the agents that have a value in period it, counts the
+ * number of those agents (nout = 11+nnst+nnd+neq columns as in egdst_simulate).  Deterministic summation order. */
+int egdst_simulate_moments(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
+                           long long nrand, int rndtype, double *means /* [nout*nt] */, int *counts /* [nout*nt] */);
+
 /* Model-function accessor behind egdstmodel.call (egdst_call.c:17-164; egdstmodel.m:1181-1207).  sw: 1 utility
  * (it, ist, id, consumption), 2 marginal utility (same), 3 discount (it, ist), 4 budget (it, ist, id, savings, ist1,
  * shock), 5 marginal budget (same), 6 value function from the solved tables (it, ist, cash).  args: host, [narg x ncol]

@@ -300,3 +300,29 @@ def test_class_surface_call():
     from egdst_amd import EgdstError
     with pytest.raises(EgdstError):
         m.call('nonsense', args)
+
+
+def test_simulated_moments_on_device():
+    """egdst_simulate_moments: per-period means of the simulated columns computed on the device equal
+    the means of the oracle's simulated paths (summation order differs: 1e-13 relative), the counts exactly."""
+    m = examples.retirement2()
+    s = gpu_solve(m)
+    ref = Oracle(m)
+    rsol = ref.solve()
+    rng = np.random.default_rng(21)
+    nsim = 5000
+    init = np.column_stack([np.ones(nsim), rng.uniform(m.a0 - 1, m.mmax + 1, nsim)])   # a few outside [a0, mmax]
+    rs = rng.random(4 * s.nt * nsim)
+    means, counts = s.simulate_moments(init, rs)
+    rsims = ref.sim(rsol, init, rs)
+    rcounts = (~np.isnan(rsims)).sum(axis=0)
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            rmeans = np.nanmean(rsims, axis=0)
+    assert np.array_equal(counts, rcounts)
+    assert np.array_equal(np.isnan(means), np.isnan(rmeans))
+    fin = np.isfinite(rmeans)
+    assert np.all(np.abs(means[fin] - rmeans[fin]) <= 1e-13 * np.maximum(1, np.abs(rmeans[fin])))
+    assert 0 < counts[0, 0] < nsim and counts[-1, 0] <= counts[0, 0]

@@ -106,3 +106,42 @@ def test_model_function_accessor(args):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'call mismatches: 0' in r.stdout, r.stdout + r.stderr[-2000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+def test_simulated_moments_kernel():
+    """k_moments under ASan: counts and means of the simulated columns equal numpy's over the same simulated paths."""
+    code = r'''
+import os, sys
+ROOT = %r
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tests', 'cpu_emu'))
+import warnings
+import numpy as np
+import build_emu
+from egdst_amd import build, codegen, examples, runtime
+m = examples.retirement2(T=8, ngridm=60)
+text = codegen.generate_modelspec(m)
+d = os.path.join(build.MODELS_DIR, build.model_tag(m, text))
+os.makedirs(d, exist_ok=True); open(os.path.join(d, 'modelspec.h'), 'w').write(text)
+lib = runtime.ModelLibrary(build_emu.build(d, 'address', 1, False, 1))
+s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
+s.set_params(m.param_vector()); s.solve()
+rng = np.random.default_rng(1)
+nsim = 200
+init = np.column_stack([np.ones(nsim), rng.uniform(-6, 11, nsim)])
+rs = rng.random(4 * s.nt * nsim)
+means, counts = s.simulate_moments(init, rs)
+sims = s.simulate(init, rs)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    ref = np.nanmean(sims, axis=0)
+ok = np.array_equal(counts, (~np.isnan(sims)).sum(axis=0)) and np.array_equal(np.isnan(means), np.isnan(ref))
+fin = np.isfinite(ref)
+ok = ok and np.all(np.abs(means[fin] - ref[fin]) <= 1e-13 * np.maximum(1, np.abs(ref[fin])))
+print('moments ok', ok)
+''' % os.path.dirname(HERE)
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'moments ok True' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr, r.stderr[-3000:]
