@@ -23,6 +23,8 @@ for i in range(nd):
     ok = ((st[i] == 0) == (r.rc == 0)) and (st[i] != 0 or ev[i] == r.nevals)
     if st[i] != 0 and r.rc != 0:
         ok = ok and lib.lib.egdst_strerror(int(st[i])).decode().strip() == r.err.strip()
+    if i % 256 == 255:
+        print('... %d draws checked, %d mismatches' % (i + 1, bad), flush=True)   # (a long silent run looks hung to gpurun)
     if not ok:
         bad += 1
         print('MISMATCH draw', i, P[i].round(4).tolist(), 'gpu', st[i], wh[i].tolist(), ev[i], '| oracle', r.rc, r.err.strip()[:50], r.nevals, flush=True)
