@@ -51,7 +51,8 @@ def build_model(model, build_dir=None, force=False, extra_flags=()):
     lib = os.path.join(d, 'libegdst.so')
     newest = max(os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES)
     newest = max(newest, os.path.getmtime(spec), os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst.h')),
-                 os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst_math.h')))
+                 os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst_math.h')),
+                 os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst_math_tables.h')))
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
         cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ['-I', d, '-I', CSRC, '-I', os.path.join(HERE, '..', 'include'),
                                                               os.path.join(CSRC, 'egdst_kernels.hip'), '-o', lib]

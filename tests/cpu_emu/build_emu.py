@@ -12,11 +12,11 @@ def build(spec_dir, sanitize=True, env_bs=1, parallel_blocks=False, wave=1, fix_
     """sanitize: True/'address' -> ASan+UBSan, 'thread' -> TSan (use env_bs>1), False -> none."""
     kind = 'address' if sanitize is True else sanitize
     out = os.path.join(spec_dir, 'libegdst_cpuemu_%s_%d_w%d_f%d%s.so' % (kind or 'plain', env_bs, wave, fix_waves, '_pb' if parallel_blocks else ''))
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(spec_dir, 'modelspec.h'),
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(spec_dir, 'modelspec.h'), os.path.join(ROOT, 'include', 'egdst_math.h'),
                                                                   os.path.join(HERE, 'hip', 'hip_runtime.h')]
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
         return out
-    cmd = ['g++', '-x', 'c++', '-std=c++17', '-O1', '-g', '-ffp-contract=off', '-fPIC', '-shared',
+    cmd = ['g++', '-x', 'c++', '-std=c++17', '-O1', '-g', '-mfma', '-ffp-contract=off', '-fPIC', '-shared',
            '-DEGDST_EMU', '-DWAVE=%d' % wave, '-DGRID_BS=1', '-DENV_BS_EMU=%d' % env_bs, '-DFIX_BS=%d' % (1 if parallel_blocks else fix_waves * wave), '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
            '-Wno-unused-function', os.path.join(CSRC, 'egdst_kernels.hip'), '-o', out]
     if os.environ.get('EMU_SEQ_WALK'):

@@ -122,20 +122,26 @@ def test_batched_draws_equal_single_draw_solves():
 
 
 def test_full_size_batch_properties():
-    """C2 at full size, 64 draws: no failures, eval counts equal the oracle's on a sample, grids monotone."""
+    """C2 at full size, 64 draws: every draw succeeds or fails as in the oracle (about 1 % of the parameter draws break
+    the reference algorithm itself), eval counts equal the oracle's, grids monotone."""
     m, gen = workloads.c2()
     P = gen(64)
     s = gpu_solve(m, P, keep_history=True)
     st, _ = s.status()
-    assert np.all(st == 0), st
     ev = s.evals()[1]
     orc = Oracle(m)
-    for i in (0, 17, 63):
-        assert ev[i] == orc.solve(P[i]).nevals
+    refs = [orc.solve(p) for p in P]
+    assert [int(x != 0) for x in st] == [int(r.rc != 0) for r in refs], st
+    assert sum(r.rc != 0 for r in refs) <= 3
+    for i, r in enumerate(refs):
+        if r.rc == 0:
+            assert ev[i] == r.nevals, i
     sol = s.solution(33)
+    assert refs[33].rc == 0
     for it in range(sol.nt):
         n = sol.len[it, 0]
         assert n >= 2 and sol.M[it, 0, 0] == m.a0 and sol.C[it, 0, 0] == 0
+        assert np.all(np.diff(sol.M[it, 0, :n]) >= 0)
 
 
 def test_errors_are_reported_not_hidden():
@@ -150,7 +156,7 @@ def test_errors_are_reported_not_hidden():
         s.solve(raise_on_error=True)
 
 
-DEGENERATE = (550, 348, 293)   # draws of workloads.c2() on which the reference algorithm itself breaks down
+DEGENERATE = (67, 9, 771)   # draws of workloads.c2() on which the reference algorithm itself breaks down
 
 
 def test_degenerate_draws_fail_like_the_oracle_with_pingpong_tables():
@@ -221,7 +227,7 @@ def test_history_based_schedule_does_not_change_results():
     """After a solve the handle moves draws with degenerate guess streams to lanes of their own (egdst_set_adaptive);
     the next solves must give the same per-draw status, evaluation counts and objective values."""
     m, gen = workloads.c2()
-    P = gen(1024)[[0, 550, 3, 348, 5, 7, 11, 13]]
+    P = gen(1024)[[0, 771, 3, 982, 5, 7, 11, 13]]
     lib = build.build_model(m)
     s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=False)
     s.set_groups(2)

@@ -55,16 +55,16 @@ def test_compact_capacity_overflow_is_redone_exactly():
 
 
 def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
-    """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=12): with ping-pong
-    tables the failure must be the oracle's (error 15 at it=11), not a success built on stale rows."""
-    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_draws.py'), '550'],
+    """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=27): with ping-pong
+    tables the failure must be the oracle's (error 15 at it=26), not a success built on stale rows."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_draws.py'), '67'],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('keep_history')]
     assert len(lines) == 2, r.stdout
     for ln in lines:
         st, where, ev, ref_rc = eval(ln.split(' ', 3)[3])
-        assert st == 15 and where == (11, 0) and ref_rc != 0, ln
+        assert st == 15 and where == (26, 0) and ref_rc != 0, ln
 
 
 def test_plain_sequential_walk_build_agrees():
