@@ -1184,7 +1184,13 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
         return;                                          \
     } while (0)
 #ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
-#define EG_DYN_LDS(name) static double name[20480]
+#define EG_DYN_LDS(name) static double name[20480 + 64]
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define EG_EMU_POISON(p, n) __asan_poison_memory_region((const void *)(p), (n))
+#else
+#define EG_EMU_POISON(p, n) ((void)0)
+#endif
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
 #endif
@@ -1348,9 +1354,19 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
+#ifdef EGDST_EMU
+    // sanitizer harness: 64 poisoned bytes between the LDS regions, so that an overrun of one region into the next
+    // traps under AddressSanitizer instead of landing in a neighbour silently
+    eg_ldsd *R1 = (eg_ldsd *)dynlds, *R2 = R1 + lcap + 8, *R3 = R2 + lcap + 8;
+    eg_ldsi *Lq = (eg_ldsi *)(R3 + lcap + 8);
+    eg_ldss *Lf = (eg_ldss *)(Lq + lcap + 16), *Lr = Lf + lcap + 32;
+    EG_EMU_POISON(R1 + lcap, 64), EG_EMU_POISON(R2 + lcap, 64), EG_EMU_POISON(R3 + lcap, 64), EG_EMU_POISON(Lq + lcap, 64),
+        EG_EMU_POISON(Lf + lcap, 64), EG_EMU_POISON(Lr + lcap, 64);
+#else
     eg_ldsd *R1 = (eg_ldsd *)dynlds, *R2 = R1 + lcap, *R3 = R2 + lcap;
     eg_ldsi *Lq = (eg_ldsi *)(R3 + lcap);            // class words
     eg_ldss *Lf = (eg_ldss *)(Lq + lcap), *Lr = Lf + lcap;  // function ids, position lists
+#endif
     eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
 
     WalkJob job;
@@ -2171,6 +2187,41 @@ __global__ void k_objective(Batch b, double *out)
     const bool ok = b.status[draw] == 0 && b.tlen[k] >= 2;
     out[2 * draw] = ok ? b.tV[k * b.g.Sp + 1] : NAN;
     out[2 * draw + 1] = ok ? b.tC[k * b.g.Sp + 1] : NAN;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Checksum of every cell of one draw: the wrapping 64-bit sums of the bit patterns of the M, C, V rows (0..len-1) and
+// of the TH, D entries (0..thlen-1); out[(it*MS_NST+ist)*5 + {0..4}].  Equal sums <=> bit-identical tables (up to 2^-64
+// luck), so a full-size solution is compared with a committed fixture without moving gigabytes (tests/golden/big_*.npz).
+#define CHK_BS 256
+__global__ void __launch_bounds__(CHK_BS) k_checksum(Batch b, int draw, unsigned long long *out)
+{
+    __shared__ unsigned long long sh[CHK_BS];
+    const int it = blockIdx.x / MS_NST, ist = blockIdx.x % MS_NST, tid = threadIdx.x;
+    const Tab t = eg_tab(b, it, draw, ist);  // (history kept: slot = period)
+    const double *cols[5] = {t.M, t.C, t.V, t.TH, t.D};
+    for (int c = 0; c < 5; c++) {
+        const int n = c < 3 ? t.len : t.thlen;
+        unsigned long long acc = 0;
+        for (int i = tid; i < n; i += CHK_BS) acc += egm_bits(cols[c][i]);
+        sh[tid] = acc;
+        __syncthreads();
+        for (int o = CHK_BS / 2; o > 0; o >>= 1) {
+            if (tid < o) sh[tid] += sh[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) out[(size_t)blockIdx.x * 5 + c] = sh[0];
+        __syncthreads();
+    }
+}
+
+// The device's exp / log / pow on caller-supplied arguments (diagnostics: they must equal the host libm bit for bit,
+// include/egdst_math.h).  fn: 0 exp(x), 1 log(x), 2 pow(x, y).
+__global__ void k_math_eval(int fn, int n, const double *x, const double *y, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = fn == 0 ? MS_EXP(x[i]) : (fn == 1 ? MS_LOG(x[i]) : MS_POW(x[i], y[i]));
 }
 
 #include "egdst_host.inc"

@@ -31,7 +31,8 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments']
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments',
+               'egdst_get_checksums', 'egdst_math_eval']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -92,6 +93,8 @@ class ModelLibrary:
         L.egdst_objective_dev.argtypes = [C.c_void_p, C.c_void_p]
         L.egdst_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.egdst_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+        L.egdst_get_checksums.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.egdst_math_eval.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.egdst_device_tables.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4
         info = EgdstModelInfo()
         L.egdst_get_model_info(C.byref(info))
@@ -100,6 +103,14 @@ class ModelLibrary:
     def check(self, rc):
         if rc != 0:
             raise EgdstRuntimeError(rc, (self.lib.egdst_last_error() or b'').decode(errors='replace'))
+
+    def math_eval(self, fn, x, y=None):
+        """The device's exp ('exp'), log ('log'), pow ('pow') on host arrays (egdst_math_eval)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(x if y is None else y, dtype=np.float64)
+        out = np.zeros_like(x)
+        self.check(self.lib.egdst_math_eval({'exp': 0, 'log': 1, 'pow': 2}[fn], x.size, _dp(x), _dp(y), _dp(out)))
+        return out
 
 
 class Solution:
@@ -300,6 +311,22 @@ class Solver:
         sol.err = self.lib.lib.egdst_strerror(sol.status).decode() if sol.status else ''
         sol.nevals = int(self.evals()[1][draw])
         return sol
+
+    def checksums(self, draw=0):
+        """[nt, nst, 5] uint64 checksums of the draw's cells (columns M, C, V, TH, D), computed on the device."""
+        if len(self._redo) and self._route(draw)[0] is not self:
+            s_, j_ = self._route(draw)
+            return s_.checksums(j_)
+        out = np.zeros((self.nt, self.lib.info.nst, 5), dtype=np.uint64)
+        self.lib.check(self.lib.lib.egdst_get_checksums(self.h, draw, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def dims(self, draw=0):
+        """(len, thlen) [nt, nst] of the draw's cells without copying the tables."""
+        ln = np.zeros((self.nt, self.lib.info.nst), dtype=np.int32)
+        th = np.zeros((self.nt, self.lib.info.nst), dtype=np.int32)
+        self.lib.check(self.lib.lib.egdst_get_solution(self.h, draw, _ip(ln), _ip(th), None, None, None, None, None))
+        return ln, th
 
     def objective_dev(self, dev_ptr):
         """Device-side objective of THIS handle's draws (draws redone after a capacity overflow read NaN here;

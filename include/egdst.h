@@ -177,6 +177,15 @@ int egdst_get_profile(egdst_handle *h, double *ms /* [3] */, int *launches /* [3
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);
 
+/* Checksums of one draw's solution, computed on the device: out[(it*nst+ist)*5 + k] = wrapping 64-bit sum of the bit
+ * patterns of column k in {M, C, V} over the cell's rows and of {TH, D} over its thresholds.  Lets a caller (and the
+ * parity tests at BASELINE.json's full sizes) compare whole solutions without exporting them.  Requires keep_history=1. */
+int egdst_get_checksums(egdst_handle *h, int draw, unsigned long long *out /* [nt*nst*5] */);
+
+/* Diagnostics: this library's device exp (fn 0), log (1), pow (2) on host arrays x, y (y only for pow), n values.
+ * include/egdst_math.h restates glibc's algorithms so that these equal the host libm bit for bit. */
+int egdst_math_eval(int fn, int n, const double *x, const double *y, double *out);
+
 /* Raw device views for callers that keep data resident (bench, estimation loops). */
 int egdst_device_tables(egdst_handle *h, int it, const double **M_dev, const double **C_dev, const double **V_dev,
                         const int **len_dev);

@@ -1,0 +1,97 @@
+"""GPU parity at BASELINE.json's full sizes against the committed fixtures of the glibc oracle (tests/golden/big_*.npz):
+rows and thresholds of every cell, evaluation count and the per-cell checksums of M, C, V, TH, D -- i.e. the complete
+solution bit for bit -- without running the oracle on the GPU box (C5 at T=100, n=32768 takes it 220 s per draw).
+Checksums are computed on the device (egdst_get_checksums); for the smaller cases the exported tables are checksummed on
+the host as well, which ties the device kernel to numpy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from egdst_amd import build, runtime, workloads
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from make_golden_big import BIG, cell_sums  # noqa: E402
+from test_big_fixtures import check_solution_against_fixture, load  # noqa: E402
+
+
+class _Dims:
+    def __init__(self, ln, th, nevals):
+        self.len, self.thlen, self.nevals = ln, th, nevals
+
+
+def solve_batch(m, P, keep_history=True):
+    lib = build.build_model(m)
+    s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=keep_history)
+    s.set_params(np.atleast_2d(P))
+    s.solve(raise_on_error=False)
+    return s
+
+
+def check_draw(s, draw, g):
+    assert s.status()[0][draw] == 0
+    ln, th = s.dims(draw)
+    check_solution_against_fixture(_Dims(ln, th, s.evals()[1][draw]), g, sums=s.checksums(draw))
+
+
+@pytest.mark.parametrize('name', ['C1', 'C2', 'C2_a0m5', 'C3', 'C4', 'C5_T60_n2000'])
+def test_full_size_configs_equal_the_glibc_fixtures(name):
+    g = load(name)
+    m, par = BIG[name][0]()
+    s = solve_batch(m, m.param_vector() if par is None else par)
+    check_draw(s, 0, g)
+    if name in ('C1', 'C2', 'C2_a0m5', 'C3'):
+        sol = s.solution(0)
+        assert np.array_equal(cell_sums(sol), s.checksums(0))   # the device checksum is the host's
+        nt, nst = sol.len.shape
+        for it in range(nt):
+            for ist in range(nst):
+                if sol.len[it, ist]:
+                    assert sol.M[it, ist, sol.len[it, ist] - 1] == g['lastM'][it, ist]
+    s.close()
+
+
+def test_c5_full_size_four_draws_one_batch():
+    """BASELINE configs[4] at T=100, n=32768, ny=15: draws 0..3 of the 1024-draw batch solved together."""
+    m, gen = workloads.c5()
+    P = gen(1024)[:4]
+    s = solve_batch(m, P)
+    for i in range(4):
+        g = load('C5_full_draw%d' % i)
+        assert np.array_equal(g['params'], P[i])
+        check_draw(s, i, g)
+    s.close()
+
+
+def test_c4_per_gpu_share_32_draws():
+    """BASELINE configs[3]: 256 draws over 8 GPUs = 32 per GPU.  Draw 5 equals its fixture; every draw solves, and the
+    batch result of a draw equals its single-draw solve (checksums)."""
+    m, gen = workloads.c4()
+    P = gen(256)[:32]
+    s = solve_batch(m, P)
+    assert np.all(s.status()[0] == 0)
+    check_draw(s, 5, load('C4_draw5'))
+    one = solve_batch(m, P[17])
+    assert np.array_equal(one.checksums(0), s.checksums(17)) and one.evals()[1][0] == s.evals()[1][17]
+    one.close()
+    s.close()
+
+
+def test_c5_batch_16_draws_full_size():
+    """A 16-draw slice of the C5 estimation batch at full size: draws 0..3 equal their fixtures inside the bigger batch
+    (other grouping, other neighbours), and a draw without a fixture equals its single-draw solve."""
+    m, gen = workloads.c5()
+    P = gen(1024)[:16]
+    s = solve_batch(m, P)
+    st = s.status()[0]
+    for i in range(4):
+        check_draw(s, i, load('C5_full_draw%d' % i))
+    j = int(np.nonzero(st == 0)[0][-1])
+    one = solve_batch(m, P[j])
+    assert one.status()[0][0] == 0
+    assert np.array_equal(one.checksums(0), s.checksums(j)) and one.evals()[1][0] == s.evals()[1][j]
+    one.close()
+    s.close()

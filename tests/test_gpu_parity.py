@@ -1,10 +1,10 @@
 """GPU parity tests proper: every call goes through the C ABI of the per-model HIP library.
 
-* shipped example models and scaled configs: bit-for-bit equal to the CPU oracle (same arithmetic, see
-  include/egdst_math.h) -- rows, thresholds, decisions, M/C/V and the evaluation count;
-* committed golden fixtures (tests/golden/*_portable.npz): exact; (*_native.npz, the reference's glibc
-  arithmetic): structure identical where the algorithm is stable and values within 5e-12, far inside the 1e-10
-  of BASELINE.json;
+* shipped example models and scaled configs: bit-for-bit equal to the CPU oracle -- rows, thresholds, decisions,
+  M/C/V and the evaluation count (the oracle build that shares include/egdst_math.h with the device; that header
+  restates glibc's exp/log/pow bit for bit, so the glibc build of the oracle gives the same numbers);
+* committed golden fixtures: tests/golden/*_portable.npz and *_native.npz (generated with the platform libm, the
+  arithmetic the reference MEX runs on): both exact (full sizes: tests/test_gpu_big.py);
 * simulator: bit-for-bit equal to the oracle's;
 * batched draws (with ping-pong tables): every draw equals its single-draw solve;
 * full-size properties (C2 batch): finite, monotone grids; evaluation counts equal the oracle's on a sample.
@@ -66,7 +66,7 @@ def test_golden_fixtures(name):
     sol = s.solution(0)
     check_against_golden(sol, np.load(os.path.join(HERE, 'golden', name + '_portable.npz')), exact=True)
     g = np.load(os.path.join(HERE, 'golden', name + '_native.npz'))     # the reference's own arithmetic
-    check_against_golden(sol, g, exact=False)
+    check_against_golden(sol, g, exact=True)
     sims = s.simulate(g['sim_init'], g['sim_rand'])
     gp = np.load(os.path.join(HERE, 'golden', name + '_portable.npz'))
     assert np.array_equal(sims, gp['sims'], equal_nan=True)
@@ -332,3 +332,26 @@ def test_simulated_moments_on_device():
     fin = np.isfinite(rmeans)
     assert np.all(np.abs(means[fin] - rmeans[fin]) <= 1e-13 * np.maximum(1, np.abs(rmeans[fin])))
     assert 0 < counts[0, 0] < nsim and counts[-1, 0] <= counts[0, 0]
+
+
+def test_device_math_equals_host_libm():
+    """exp / log / pow on the device == glibc's (x86-64 FMA variant), bit for bit: against vectors committed from this
+    image's libm (tests/golden/math_vectors.npz) and against the GPU box's own libm through ctypes."""
+    from test_math_vs_libm import _glibc_fma_variant
+    sys_path = os.path.join(HERE, 'golden')
+    import sys
+    sys.path.insert(0, sys_path)
+    from make_math_vectors import libm
+    lib = build.build_model(examples.occ3())
+    g = np.load(os.path.join(HERE, 'golden', 'math_vectors.npz'))
+    e, l, p = lib.math_eval('exp', g['exp_x']), lib.math_eval('log', g['log_x']), lib.math_eval('pow', g['pow_a'], g['pow_b'])
+    assert np.array_equal(e, g['exp_y'], equal_nan=True)
+    assert np.array_equal(l, g['log_y'], equal_nan=True)
+    assert np.array_equal(p, g['pow_y'], equal_nan=True)
+    assert np.array_equal(np.signbit(p), np.signbit(g['pow_y']))       # (-0.0 vs 0.0)
+    if _glibc_fma_variant():
+        m = libm()
+        x = np.random.default_rng(5).uniform(-30, 30, 20000)
+        assert np.array_equal(lib.math_eval('exp', x), np.array([m.exp(v) for v in x]))
+        assert np.array_equal(lib.math_eval('log', np.abs(x)), np.array([m.log(abs(v)) for v in x]))
+        assert np.array_equal(lib.math_eval('pow', np.abs(x), x / 7), np.array([m.pow(abs(v), v / 7) for v in x]))

@@ -29,6 +29,20 @@ def test_device_code_is_asan_clean_and_bit_exact(args):
 
 
 @pytest.mark.skipif(_asan() is None, reason='libasan not found')
+def test_the_round1_fault_case_is_clean_with_every_array_in_its_own_allocation():
+    """Round 1 saw a GPU memory fault in k_envelope on this very input (8-state model, T=12, ngridm=150, ny=5: 14 492
+    rows, 401 608 evaluations) in builds whose walk was NOT inlined.  Under the harness every device array is its own
+    heap block and the LDS regions are separated by poisoned gaps, so an overrun from one array into its neighbour --
+    invisible while everything was carved from one pool -- would trap here.  It does not."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py'), 'retirement8', 'T=12, ngridm=150, ny=5'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'rows=14492/14492 evals=401608/401608 max_rel=0.00e+00' in r.stdout, r.stdout
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
 def test_batched_draws_and_pingpong_tables():
     env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
     r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_batch.py'), '60', '12', '4'], env=env,
