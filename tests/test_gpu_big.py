@@ -25,8 +25,9 @@ class _Dims:
 
 def solve_batch(m, P, keep_history=True):
     lib = build.build_model(m)
+    P = np.atleast_2d(np.asarray(P, dtype=np.float64))
     s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=keep_history)
-    s.set_params(np.atleast_2d(P))
+    s.set_params(P)
     s.solve(raise_on_error=False)
     return s
 
