@@ -136,6 +136,29 @@ class _Rewriter:
         return _TOK.sub(sub, text)
 
 
+
+def _mentions(model, expr, words, seen=None):
+    """Does the executable string (or any equation it references, recursively) use one of `words` as an identifier?"""
+    seen = set() if seen is None else seen
+    eqs = {e.ref: e for e in model.eq}
+    for ln in _lines(expr):
+        for mo in _TOK.finditer(ln):
+            t = mo.group('id')
+            if not t:
+                continue
+            if t in words:
+                return True
+            if t in eqs and t not in seen:
+                seen.add(t)
+                if _mentions(model, eqs[t].expression, words, seen):
+                    return True
+            if t in ('mu', 'sigma') and t not in seen:   # mu may be written in terms of sigma (and vice versa)
+                seen.add(t)
+                if _mentions(model, model.shock[t], words, seen):
+                    return True
+    return False
+
+
 def analyse_optim(model):
     """Optimisation flags exactly as compile.m:669-747 derives them (regex on the raw strings)."""
     def joined(x):
@@ -214,6 +237,10 @@ def generate_modelspec(model):
     w('#define MS_DISTRIB %d' % (1 if m.shock['type'] == 'lognormal' else 2))
     for k in ('optim_MUnoD', 'optim_UnoD', 'optim_UasD', 'optim_TRPRnoSH'):
         w('#define MS_%s %d' % (k.upper(), int(optim[k])))
+    # 1: mu and sigma of the shock do not depend on savings (nor on cash): the nodes exp(mu + z*sigma) of a
+    # (current state, decision, next state) are the same for every end-of-period asset point (device: computed once per workgroup)
+    w('#define MS_SHOCK_NODES_SHARED %d' % int(not (_mentions(m, m.shock['mu'], ('savings', 'cash', 'shock')) or
+                                                   _mentions(m, m.shock['sigma'], ('savings', 'cash', 'shock')))))
     for k in ('TOLERANCE', 'ZEROCONSUMPTION', 'DOUBLEPOINT_DELTA'):
         w('#define MS_%s (%s)' % (k, m.cflags[k]))
     w('#define MS_MAX(X,Y) (((X)>(Y))?(X):(Y))')

@@ -43,6 +43,17 @@
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
 #endif
 
+#ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
+#define EG_DYN_LDS(name) static double name[20480 + 64]
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define EG_EMU_POISON(p, n) __asan_poison_memory_region((const void *)(p), (n))
+#else
+#define EG_EMU_POISON(p, n) ((void)0)
+#endif
+#else
+#define EG_DYN_LDS(name) extern __shared__ double name[]
+#endif
 #include "egdst_device.h"
 #include "egdst_envelope.h"
 #include "../../include/egdst.h"
@@ -786,6 +797,232 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_grid with the searched columns in LDS (batches that fill the GPU).  Counters of round 2 on C2 x 4096
+// (profiles/r02_pmc_c2_4096.csv): k_grid executes ~360 vector instructions and 22 dependent global loads per
+// evaluation and its waves wait 63 % of their cycles.  Three changes, none of which touches a floating-point operation:
+//   * the M column of every next-period table a lane can reach is staged in LDS once per workgroup (8 B per row), so the
+//     bracket search is 32-bit LDS addressing instead of dependent L2 round trips; C and V are read at the bracket only;
+//   * ONE bracket search per evaluation: valuefunc searches the same column shifted by one row (egdst_solver.c:768,
+//     egdst_lib.c:179-206), and on a non-decreasing column its bracket follows from the first one (eg_second_bracket);
+//     the workgroup checks the order while staging and falls back to the two searches otherwise;
+//   * the shock nodes exp(mu + z sigma) of a (state, decision, next state) do not depend on the asset point when mu and
+//     sigma do not (MS_SHOCK_NODES_SHARED, found by the code generator): computed once per workgroup.
+// Same arithmetic per evaluation as eg_lane_eval / eg_term / eg_next_value, same order of accumulation.
+#ifndef EG_GRID_LROWS_MAX
+#define EG_GRID_LROWS_MAX 4096  // rows of M columns (all next states together) a workgroup may stage: 32 KB
+#endif
+#define EG_GRID_NYMAX 32        // shock nodes kept per next state
+
+// bracket of valuefunc's search over (M+1, len-1) given the bracket i of linter's search over (M, len), for a
+// non-decreasing column with len >= 4 (both searches return "the last row <= x" clamped to their ranges)
+static __device__ __forceinline__ int eg_second_bracket(double x, int i, double m2, double mlast2, int n1)
+{
+    return (x < m2) ? 0 : ((x >= mlast2) ? n1 - 3 : i - 1);
+}
+
+// eg_term + eg_next_value for keep == 1 with the M column in LDS and one search (see above)
+static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_ldsd *M, const Tab &t, const ms_pv *cur, ms_pv *nxt,
+                                                     double pr1, double *t_rhs, double *t_evf)
+{
+    nxt->cash = ms_cashinhand(E, cur, nxt);
+    const double x = nxt->cash;
+    const int n1 = t.len;
+    const int i = eg_bracket(x, M, n1, 0);
+    const double mlast = M[n1 - 1], mfirst = M[1];
+    double c1 = eg_lerp(x, M[i], M[i + 1], t.C[i], t.C[i + 1]);
+    if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
+    *t_rhs = 0;
+    *t_evf = 0;
+    if (c1 <= 0) return c1;
+    if (!MS_OPTIM_MUNOD || (!MS_OPTIM_UNOD && x < mfirst))
+        nxt->id = (int)t.D[eg_bracket(x, t.TH, t.thlen, 1)];  // optimd, egdst_lib.c:129-132
+    else
+        nxt->id = 0;
+    *t_rhs = pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
+    const double evf1 = t.V[0], a0 = E->a0;
+    double val;
+    if (x < mfirst && evf1 > -INFINITY)
+        val = ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
+    else {
+        const int j = eg_second_bracket(x, i, M[2], M[n1 - 2], n1);  // == eg_bracket(x, M + 1, n1 - 1, 0)
+        const double f0 = t.V[j + 1], f1 = t.V[j + 2];
+        if (!isfinite(f0))
+            val = f0;
+        else if (!isfinite(f1))
+            val = f1;
+        else {
+            const double g0 = M[j + 1], g1 = M[j + 2];
+            if (x > a0 && (x > mlast || x < mfirst)) {
+                const double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
+                val = f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
+            } else
+                val = eg_lerp(x, g0, g1, f0, f1);
+        }
+    }
+    *t_evf = pr1 * val;
+    return c1;
+}
+
+__global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows)
+{
+    EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
+    __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded
+    __shared__ double gl_shock[MS_SHOCK_NODES_SHARED ? MS_NST * EG_GRID_NYMAX : 1];
+    __shared__ int gl_niy[MS_NST];
+    const int combo = blockIdx.y;
+    const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
+    const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
+    if (b.status[draw]) return;
+    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
+    if (!P.active || !P.grid) return;  // (uniform over the workgroup)
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it;
+    cur.ist = ist;
+    cur.id = id;
+    cur.cash = cur.savings = cur.shock = 0;
+    const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+    const int ny = b.g.ny;
+    eg_ldsd *LM = (eg_ldsd *)gl_dyn;
+    // ---- stage: which next states, how many rows, are the columns in order -------------------------------------
+    if (threadIdx.x == 0) {
+        int tot = 0, ok = (ny <= EG_GRID_NYMAX || !MS_SHOCK_NODES_SHARED) ? 1 : 0;
+        ms_pv nx;
+        nx.it = it + 1, nx.id = 0, nx.cash = nx.shock = 0, nx.savings = 0;
+        for (nx.ist = 0; nx.ist < MS_NST; nx.ist++) {
+            gl_off[nx.ist] = -1;
+            if (ms_feasible(&E, &nx) != 1) continue;
+            const size_t k = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + nx.ist;
+            const int len = b.tlen[k];
+            if (len < 4 || len > b.g.Sp || tot + len > lrows) {  // (short or missing tables: the general path reports them)
+                ok = 0;
+                break;
+            }
+            gl_off[nx.ist] = tot;
+            tot += len;
+        }
+        gl_ok = ok;
+    }
+    __syncthreads();
+    bool fast = gl_ok != 0;
+    if (fast) {
+        int bad = 0;
+        ms_pv nx;
+        nx.it = it + 1, nx.id = 0, nx.cash = nx.shock = 0, nx.savings = 0;
+        for (int s1 = 0; s1 < MS_NST; s1++) {
+            const int off = gl_off[s1];
+            if (off < 0) continue;
+            const Tab t = eg_tab(b, slot1, draw, s1);
+            for (int r = threadIdx.x; r < t.len; r += GRID_BS) {
+                const double m = t.M[r];
+                LM[off + r] = m;
+                if (r + 1 < t.len && !(m <= t.M[r + 1])) bad = 1;  // (NaN counts as out of order)
+            }
+            if (MS_SHOCK_NODES_SHARED) {
+                nx.ist = s1;
+                const int niy = (ms_sigma(&E, &cur, &nx) <= 0 || ny == 1) ? 1 : ny;
+                if (threadIdx.x == 0) gl_niy[s1] = niy;
+                for (int iy = threadIdx.x; iy < niy; iy += GRID_BS)
+                    gl_shock[s1 * EG_GRID_NYMAX + iy] = (niy == 1) ? eg_shock_mean(&E, &cur, &nx) : eg_shock_node(&E, &cur, &nx, b.qz[iy]);
+            }
+        }
+        if (bad) gl_ok = 0;  // (benign race: every writer stores 0)
+        __syncthreads();
+        fast = gl_ok != 0;
+    }
+    if (n >= b.g.ngridm) return;
+    GridLims L;
+    L.lim1 = P.lim1, L.lim2 = P.lim2, L.lim3 = P.lim3, L.lim3p = P.lim3p, L.k3 = P.k3, L.ntogenerate = P.ntogenerate;
+    const double A = eg_grid_A(&E, &cur, L, 0, P.A0, n);
+    LaneEval r;
+    if (!fast)
+        r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
+    else {  // eg_lane_eval with the staged columns
+        double rhs = 0, evf = 0, checksum = 0, c1 = 1.0;
+        int status = 0, terr = 0, cnt = 0;
+        r.bist = 0;
+        r.bshock = r.bcash = 0;
+        ms_pv nxt;
+        nxt.it = it + 1;
+        nxt.id = 0;
+        nxt.cash = 0;
+        nxt.shock = 0;
+        nxt.savings = A;
+        for (nxt.ist = 0; nxt.ist < MS_NST; nxt.ist++) {
+            if (ms_feasible(&E, &nxt) != 1) continue;
+            double pr1pre = 0;
+            if (MS_OPTIM_TRPRNOSH) {
+                pr1pre = ms_trpr(&E, &cur, &nxt, &terr);
+                if (pr1pre == 0.0) continue;
+            }
+            const int niy = MS_SHOCK_NODES_SHARED ? gl_niy[nxt.ist] : ((ms_sigma(&E, &cur, &nxt) <= 0 || ny == 1) ? 1 : ny);
+            const Tab t = eg_tab(b, slot1, draw, nxt.ist);
+            if (t.thlen > b.g.nthrhmax || t.thlen < 1) {
+                status = -2707;
+                break;
+            }
+            const eg_ldsd *M = LM + gl_off[nxt.ist];
+            for (int iy = 0; iy < niy; iy++) {
+                double pr1;
+                if (MS_SHOCK_NODES_SHARED)
+                    nxt.shock = gl_shock[nxt.ist * EG_GRID_NYMAX + iy];
+                else
+                    nxt.shock = (niy == 1) ? eg_shock_mean(&E, &cur, &nxt) : eg_shock_node(&E, &cur, &nxt, b.qz[iy]);
+                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
+                if (niy != 1) pr1 *= b.qw[iy];
+                if (pr1 == 0.0) continue;
+                checksum += pr1;
+                cnt++;
+                double t_rhs, t_evf;
+                c1 = eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf);
+                if (c1 <= 0) break;
+                rhs += t_rhs;
+                evf += t_evf;
+                if (evf == -INFINITY) break;
+            }
+            if (c1 <= 0 || evf == -INFINITY) {
+                r.bist = nxt.ist;
+                r.bshock = nxt.shock;
+                r.bcash = nxt.cash;
+                break;
+            }
+        }
+        if (terr) status = -25;
+        if (status == 0) {
+            if (c1 <= 0)
+                status = 1;
+            else if (evf == -INFINITY)
+                status = 2;
+            else if (fabs(checksum - 1) > EG_TOL)
+                status = -11;
+        }
+        r.status = status;
+        r.cnt = cnt;
+        if (status == 0) {
+            rhs *= ms_discount(&E, &cur);
+            r.M = A + ms_utility_marginal_inverse(&E, &cur, rhs);
+            r.C = r.M - A;
+            r.V = ms_utility(&E, &cur, r.C) + ms_discount(&E, &cur) * evf;
+            r.R = r.M;
+        } else {
+            r.M = NAN;
+            r.C = r.V = 0;
+            r.R = (status == 1) ? b.g.a0 - 1 : r.bcash;
+        }
+    }
+    const size_t o = eg_cand(b, draw, ist, id) + n;
+    if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
+    b.cCnt[o] = r.cnt;
+    b.cSt[o] = r.status;
+    b.cR[o] = r.R;
+    b.cM[o] = r.M;
+    if (r.status == 0) {
+        b.cC[o] = r.C;
+        b.cV[o] = r.V;
+    }
+}
+
 // k_grid for small batches: 16 lanes per grid point, a lane per shock node (eg_wave_expectation with groups of 16),
 // so that a solve that leaves the GPU mostly idle does not spend 20 serial shock terms per point: same arithmetic and
 // the same order of accumulation as eg_lane_eval, 62 -> 20 us per period on a single C2 draw.
@@ -1183,17 +1420,6 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
         }                                                \
         return;                                          \
     } while (0)
-#ifdef EGDST_EMU  // the CPU sanitizer harness has no dynamic LDS: a static buffer stands in for it
-#define EG_DYN_LDS(name) static double name[20480 + 64]
-#if defined(__SANITIZE_ADDRESS__)
-#include <sanitizer/asan_interface.h>
-#define EG_EMU_POISON(p, n) __asan_poison_memory_region((const void *)(p), (n))
-#else
-#define EG_EMU_POISON(p, n) ((void)0)
-#endif
-#else
-#define EG_DYN_LDS(name) extern __shared__ double name[]
-#endif
 #define ENV_SMALLF 1024  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
                          // (C5 at full size: 292 pieces in one list; the reference allows 10000, :832)
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");

@@ -355,3 +355,20 @@ def test_device_math_equals_host_libm():
         assert np.array_equal(lib.math_eval('exp', x), np.array([m.exp(v) for v in x]))
         assert np.array_equal(lib.math_eval('log', np.abs(x)), np.array([m.log(abs(v)) for v in x]))
         assert np.array_equal(lib.math_eval('pow', np.abs(x), x / 7), np.array([m.pow(abs(v), v / 7) for v in x]))
+
+
+@pytest.mark.parametrize('name', ['retirement2', 'occ3', 'retire8', 'deaton2', 'model2', 'C2', 'C2_a0neg_T60', 'occ3_n400'])
+@pytest.mark.parametrize('lds', ['lds', 'general'])
+def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
+    """A single draw normally takes k_grid_wide (16 lanes per point).  Forced through the kernels big batches use --
+    k_grid_lds (searched columns in LDS, one bracket search per evaluation, shared shock nodes) and the general k_grid --
+    every model must still equal the oracle bit for bit."""
+    monkeypatch.setenv('EGDST_GRID_WIDE', '0')
+    monkeypatch.setenv('EGDST_GRID_LDS', '0' if lds == 'general' else '2048')
+    m = (CASES.get(name) or SCALED[name])()
+    s = gpu_solve(m)
+    sol, ref = s.solution(0), Oracle(m).solve()
+    assert ref.rc == 0 and sol.status == 0, (sol.status, sol.err, sol.where)
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    assert sol.nevals == ref.nevals
