@@ -1,27 +1,38 @@
 #!/usr/bin/env python
 """bench.py -- EGM grid-point x shock evals/s of the batched backward induction on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       (N > 1 without torchrun: this script starts the ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one full backward induction (terminal period + T-t0 EGM periods, envelopes included) of a
-batch of `--ndraw` independent parameter draws of the workload, inputs (parameter vectors, quadrature)
-resident in HBM when the timed region starts.  Weak scaling: every rank solves `--ndraw` draws of its own
-(draws are independent); the only collective is the RCCL all-reduce of the per-draw
-objective contributions after the timed steps.  Rank 0 prints ONE JSON line.
+A "step" is one full backward induction (terminal period + T-t0 EGM periods, envelopes included) of a batch of
+independent parameter draws of the workload, parameter vectors and quadrature resident in HBM when the timed region
+starts.  The draws move a little from step to step (each parameter times 1 + 0.5 % U(-1,1), as the iterations of an
+estimation loop would move them), so the handle's history-based straggler schedule is never trained on the very draws
+it then meets (--no-perturb: the same draws every step).
 
-value       = evals the REFERENCE would execute for these draws (counted on device, equal to the oracle's
-              count in the parity tests) * ranks / max-over-ranks wall time
-roofline    = algorithmic table bytes per launch of the dominant kernel / its mean HIP-event duration,
-              against the 8 TB/s HBM3E peak (the path is NOT bandwidth bound at these sizes,
-              the fraction is reported honestly)
-cpu_baseline= the CPU oracle (oracle/egdst_oracle.c, glibc math, gcc -O2, 1 thread) on a bounded sample
-              of the same draws, timed in this run on the GPU box's host
+  --scaling weak   (default) every rank solves --ndraw draws per step (BASELINE configs[1]: C2, 4096 draws per GPU)
+  --scaling strong the job is --ndraw-total draws per step (north_star: the 1024-draw C5 batch, 256 draws of C4), rank r
+                   takes the contiguous shard egdst_amd.parallel.shard_bounds gives it and loops chunks of --chunk draws
+                   that fit HBM through ONE handle
+Draws are independent: no data-path collective; after the timed steps the per-draw objective
+contributions are reduced with one RCCL all-reduce.  Rank 0 prints ONE JSON line.
+
+value       = evaluations EXECUTED for the draws that solved (failed draws and the evaluations the device credits
+              without executing -- include/egdst.h egdst_get_evals_credited -- are left out), all ranks, all timed
+              steps / max-over-ranks wall time.  `evals_reference_per_step` is what the reference would count.
+roofline    = algorithmic table bytes per launch of the dominant kernel / its mean HIP-event duration (events on the
+              group streams the kernel is launched on), against the 8 TB/s HBM3E peak; `traffic`, `valu_util`,
+              `valu_fp64_util`, `lds_GBps` from the rocprofv3 --pmc passes committed under profiles/ for this very
+              configuration (counters cannot be read from inside the process).  The path is NOT HBM-bound at these
+              sizes (SURVEY.md section 8d says so): the fraction is reported as it is.
+cpu_baseline= the CPU oracle (oracle/egdst_oracle.c, glibc math, gcc -O2) on a bounded sample of the same draws, timed in
+              this run on the GPU box's host: one thread (`value`, `cores` = 1) and all host cores, one process per draw.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,24 +42,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import egdst_amd  # noqa: E402,F401  (before torch starts the HIP runtime: sets GPU_MAX_HW_QUEUES, see egdst_amd/__init__.py)
 
+DEFAULT_CHUNK = {'C1': 4096, 'C2': 4096, 'C3': 256, 'C4': 32, 'C5': 128}   # draws per handle that fit 288 GB comfortably
 
-def cpu_baseline(model, draws, budget_s=12.0):
-    """Single-thread oracle (the 'port' of the reference CPU path) on a bounded sample of the draws."""
+
+def _oracle_worker(args):
+    """(module-level for multiprocessing) solve draws with the oracle until the budget is spent; returns (evals, n, seconds)"""
+    wl, kw, draws, budget_s = args
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from egdst_amd import workloads
     from oracle_harness import Oracle
+    model = workloads.WORKLOADS[wl](**kw)[0]
     orc = Oracle(model, native_math=True)
     t0 = time.perf_counter()
-    evals, n = 0, 0
+    evals = n = 0
     for p in draws:
-        sol = orc.solve(p)
-        evals += sol.nevals
+        evals += orc.solve(p).nevals
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {'value': evals / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d draws of the same workload, %.1f s, oracle/egdst_oracle.c gcc -O2 glibc math' % (n, dt),
-            'wall_s_per_solve': dt / max(n, 1)}
+    return evals, n, time.perf_counter() - t0
+
+
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(wl, kw, draws, budget_s=10.0, cores=None):
+    """Oracle (the 'port' of the reference CPU path) on a bounded sample: one thread, then one process per core."""
+    import multiprocessing as mp
+    ev, n, dt = _oracle_worker((wl, kw, draws, budget_s))
+    out = {'value': ev / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d draws of the same workload, %.1f s, oracle/egdst_oracle.c gcc -O2 glibc math' % (n, dt),
+           'wall_s_per_solve': dt / max(n, 1), 'cpu_model': cpu_model_name(), 'host_cores': os.cpu_count()}
+    cores = cores or min(os.cpu_count() or 1, 16)
+    if cores > 1:
+        parts = [draws[i::cores] for i in range(cores)]
+        t0 = time.perf_counter()
+        with mp.get_context('spawn').Pool(cores) as pool:
+            res = pool.map(_oracle_worker, [(wl, kw, p, budget_s * 0.6) for p in parts])
+        wall = time.perf_counter() - t0
+        busy = max(r[2] for r in res)
+        out['all_cores'] = {'value': sum(r[0] for r in res) / busy, 'unit': 'evals/s', 'cores': cores,
+                            'sample': '%d draws, one process per core, %.1f s of solving (%.1f s with start-up)' % (
+                                sum(r[1] for r in res), busy, wall)}
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start the ranks as a child process BEFORE anything touches the GPU."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_metrics(workload, ndraw, kernel):
+    """Counter-derived figures of `kernel` from the committed PMC passes of this configuration, or {}."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_metrics.json')))
+        cfg = tj.get('%s_ndraw%d' % (workload, ndraw), {})
+        return cfg.get(kernel, {})
+    except (OSError, ValueError):
+        return {}
 
 
 def main():
@@ -57,43 +121,84 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='C2')
-    ap.add_argument('--ndraw', type=int, default=4096, help='parameter draws per GPU (weak scaling)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--ndraw', type=int, default=4096, help='weak scaling: parameter draws per GPU and step')
+    ap.add_argument('--ndraw-total', type=int, default=1024, help='strong scaling: draws of the whole job per step')
+    ap.add_argument('--chunk', type=int, default=0, help='draws solved per handle at a time (0: per workload)')
     ap.add_argument('--rows-cap', type=int, default=0, help='compact physical row capacity (0 = exact, ngridmax rows)')
+    ap.add_argument('--small', action='store_true', help='reduced grid of the workload (plumbing rehearsals, not a result)')
+    ap.add_argument('--no-perturb', action='store_true', help='the same draws every step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-single-solve', action='store_true', help='skip the one-draw latency leg (profiling runs)')
+    ap.add_argument('--no-single-solve', action='store_true', help='skip the one-draw latency legs (profiling runs)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the copy-peak, export and estimation legs')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
-    from egdst_amd import build, runtime, workloads
+    from egdst_amd import build, parallel, runtime, workloads
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d' % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the egdst hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())   # (rehearsals put several ranks on one card)
     use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ   # under torchrun also with one rank
     if use_dist:
         # Rendezvous and the timing barriers go over gloo (host side).  The RCCL communicator for the path's one
         # collective is created AFTER the timed region: an initialised RCCL communicator holds hardware queues of its
-        # own, which the 21 streams of the solver then have to share (measured with one rank: 346 -> 450 ms per step).
+        # own, which the streams of the solver then have to share (measured with one rank: 346 -> 450 ms per step).
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('gloo')
 
-    model, drawgen = workloads.WORKLOADS[args.workload]()
+    wl_kw = {}
+    if args.small:
+        wl_kw = {'C2': dict(ngridm=200, T=20), 'C4': dict(ngridm=2048, T=20), 'C5': dict(ngridm=500, T=20)}.get(args.workload, {})
+    model, drawgen = workloads.WORKLOADS[args.workload](**wl_kw)
     lib = build.build_model(model)  # prebuilt in-tree by __graft_entry__.build(); rebuilds if stale
     desc = model.descriptor()
-    ndraw = args.ndraw
-    all_draws = drawgen(ndraw * world) if drawgen else np.tile(model.param_vector(), (ndraw * world, 1))
-    mine = np.ascontiguousarray(all_draws[rank * ndraw:(rank + 1) * ndraw])
+    nparam = lib.info.nparam
+
+    # ---- the draws of this rank, per step ---------------------------------------------------------------------
+    if args.scaling == 'weak':
+        job = args.ndraw * world
+        lo, hi = rank * args.ndraw, (rank + 1) * args.ndraw
+    else:
+        job = args.ndraw_total
+        lo, hi = parallel.shard_bounds(job, world, rank)
+    mine_n = hi - lo
+    chunk = args.chunk or DEFAULT_CHUNK.get(args.workload, 256)
+    chunk = max(1, min(chunk, max(mine_n, 1)))
+    nsteps_all = args.warmup + args.steps
+
+    def step_draws(s):
+        """the job's draws, moved a little from step to step as an estimation loop would move them (each parameter times
+        1 + 0.5 % * U(-1, 1), seeded by the step): close enough for the handle's history to mean something, never equal"""
+        seed = {'C4': 20240}.get(args.workload, 20241)
+        allp = drawgen(job, seed=seed) if drawgen else np.tile(model.param_vector(), (job, 1))
+        if not args.no_perturb:
+            allp = allp * (1.0 + 0.005 * (2.0 * np.random.default_rng(7919 + s).random(allp.shape) - 1.0))
+        return np.ascontiguousarray(allp[lo:hi])
+
+    host_draws = [step_draws(s) for s in range(nsteps_all)]
+    # inputs resident in HBM before the timed region: [step][draw][param], padded to whole chunks with the shard's first draw
+    nchunks = (mine_n + chunk - 1) // chunk if mine_n else 0
+    padded = nchunks * chunk
+    dev = torch.zeros(nsteps_all, max(padded, 1), max(nparam, 1), dtype=torch.float64, device='cuda')
+    for s, p in enumerate(host_draws):
+        if mine_n:
+            pp = np.concatenate([p, np.repeat(p[:1], padded - mine_n, axis=0)]) if padded > mine_n else p
+            dev[s, :padded] = torch.from_numpy(pp).cuda()
 
     stream = torch.cuda.Stream()
-    solver = runtime.Solver(lib, desc, ndraw=ndraw, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap)
-    params_dev = torch.from_numpy(mine).cuda()          # inputs resident in HBM before the timed region
-    obj = torch.zeros(ndraw, 2, dtype=torch.float64, device='cuda')
+    solver = runtime.Solver(lib, desc, ndraw=chunk, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap) if mine_n else None
+    obj = torch.full((nsteps_all, max(padded, 1), 2), float('nan'), dtype=torch.float64, device='cuda')
     torch.cuda.synchronize()
-    solver.set_params_dev(params_dev.data_ptr())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -101,40 +206,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        solver.solve_async()
-    solver.sync(raise_on_error=False)
-    solver.set_profile(True)
+    def run_step(s):
+        """one step of this rank: every chunk of its shard through the one handle; returns the counters"""
+        ev_ref = ev_exec = nfail = ndone = 0
+        for c in range(nchunks):
+            solver.set_params_dev(dev[s, c * chunk:(c + 1) * chunk].data_ptr())
+            solver.solve_async()
+            solver.sync(raise_on_error=False)
+            valid = min(chunk, mine_n - c * chunk)              # (the last chunk may be padded)
+            st, _ = solver.status()
+            per = solver.evals()[1]
+            cred = solver.evals_credited()
+            ok = st[:valid] == 0
+            ev_ref += int(per[:valid].sum())
+            ev_exec += int((per[:valid] - cred[:valid])[ok].sum())
+            nfail += int((~ok).sum())
+            ndone += valid
+            if not solver.rows_cap:
+                with torch.cuda.stream(stream):
+                    solver.objective_dev(obj[s, c * chunk:(c + 1) * chunk].data_ptr())
+            else:
+                obj[s, c * chunk:(c + 1) * chunk] = torch.from_numpy(solver.objective()).cuda()
+        return ev_ref, ev_exec, nfail, ndone
+
+    for s in range(args.warmup):
+        if solver:
+            run_step(s)
+    if solver:
+        solver.set_profile(True)
 
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.solve_async()
-    solver.sync(raise_on_error=False)
+    tot = np.zeros(4, dtype=np.int64)
+    for s in range(args.warmup, nsteps_all):
+        if solver:
+            tot += np.array(run_step(s), dtype=np.int64)
     sync_all()
     dt = time.perf_counter() - t0
 
-    status, _ = solver.status()
-    evals_step, _ = solver.evals()
-    kms, klaunch, algbytes = solver.profile()       # of the LAST step (events are re-recorded every step)
-    # final objective reduce (the only collective of the path, RCCL over xGMI when world > 1)
-    if solver.rows_cap:
-        obj = torch.from_numpy(solver.objective()).cuda()   # includes the draws redone with exact capacities
-    else:
-        with torch.cuda.stream(stream):
-            solver.objective_dev(obj.data_ptr())
-        stream.synchronize()
-    okmask = ~torch.isnan(obj[:, 0])
-    red = torch.stack([torch.where(okmask, obj[:, 0], torch.zeros_like(obj[:, 0])).sum(), okmask.sum().double()])
+    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(3), np.zeros(3, dtype=np.int32), 0)   # of the LAST solve
+    # ---- final objective reduce: the only collective of the path (RCCL over xGMI when world > 1) -----------------
+    last = obj[nsteps_all - 1, :mine_n, 0] if mine_n else torch.zeros(0, dtype=torch.float64, device='cuda')
+    okmask = ~torch.isnan(last)
+    red = torch.stack([torch.where(okmask, last, torch.zeros_like(last)).sum(), okmask.sum().double()])
     tt = torch.tensor([dt], dtype=torch.float64)
-    ev = torch.tensor([float(evals_step)], dtype=torch.float64)
+    cnt = torch.tensor(tot.astype(np.float64))
     if use_dist:
-        rccl = dist.new_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=rccl)   # objective contributions: RCCL over xGMI
+        if world <= torch.cuda.device_count():
+            rccl = dist.new_group(backend='nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=rccl)   # objective contributions: RCCL over xGMI
+        else:   # rehearsal with several ranks on one card (RCCL refuses duplicate devices): the same reduce over gloo
+            red_h = red.cpu()
+            dist.all_reduce(red_h, op=dist.ReduceOp.SUM)
+            red = red_h
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                # timing bookkeeping: host
-        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
-    evals_all = float(ev.item())
+    ev_ref_all, ev_exec_all, nfail_all, ndone_all = [float(x) for x in cnt.tolist()]
 
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
@@ -143,53 +271,72 @@ def main():
         avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
         bytes_per_launch = algbytes / max(klaunch[dom], 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # single-solve latency (one draw) for the "full backward-induction wall time" half of the metric
-        single_ms = None
-        if not args.no_single_solve and world == 1:
-            s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
-            s1.set_params(mine[:1])
-            s1.solve()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                s1.solve()
-            single_ms = (time.perf_counter() - t1) / 3 * 1e3
-            s1.close()
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the figure is
-        # the one measured by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this command and committed
-        # under profiles/ (see profiles/README.md), used only when it was taken on the same configuration
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            if (tj['workload'], tj['ndraw'], tj['rows_cap'], tj['kernel'], tj['launches_per_step']) == (
-                    args.workload, ndraw, args.rows_cap, 'k_' + names[dom], int(klaunch[dom])):
-                traffic = tj['fetch_bytes_per_launch'] + tj['write_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
+        pm = pmc_metrics(args.workload, chunk, 'k_' + names[dom]) if not args.small else {}
         out = {
             'metric': 'EGM grid-point x shock evals/sec (batched backward induction, all draws, all periods)',
-            'value': evals_all / (dt_max / args.steps), 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak',
+            'value': ev_exec_all / dt_max, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: %s, T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (
-                args.workload, model.label, desc['T'], desc['ngridm'], desc['ny'], lib.info.nd, lib.info.nst,
-                desc['a0'], desc['mmax']), 'ndraw_per_gpu': ndraw, 'ndraw_total': ndraw * world,
-                'rows_cap': args.rows_cap,
-                'parallelism': 'draws sharded over %d rank(s), no data-path collective' % world},
-            'evals_per_step': evals_all, 'failed_draws_rank0': int((status != 0).sum()),
-            'single_solve_ms': single_ms, 'capacity_retries': solver.capacity_retries,
-            'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())),
+            'config': {'workload': '%s%s: %s, T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (
+                args.workload, ' (REDUCED GRID, rehearsal only)' if args.small else '', model.label, desc['T'], desc['ngridm'],
+                desc['ny'], lib.info.nd, lib.info.nst, desc['a0'], desc['mmax']),
+                'draws_per_step_all_gpus': job, 'draws_per_gpu': args.ndraw if args.scaling == 'weak' else '%d..%d' % (job // world, -(-job // world)),
+                'chunk_draws_per_handle': chunk, 'chunks_per_step_rank0': nchunks, 'rows_cap': args.rows_cap,
+                'draws_perturbed_every_step': not args.no_perturb,
+                'parallelism': 'draws sharded over %d rank(s), no data-path collective, one RCCL all-reduce of the objective' % world},
+            'evals_executed_per_step': ev_exec_all / args.steps, 'evals_reference_per_step': ev_ref_all / args.steps,
+            'failed_draws_per_step': nfail_all / args.steps, 'draws_per_step': ndone_all / args.steps,
+            'capacity_retries': solver.capacity_retries if solver else 0,
+            'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())) if solver else {},
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
-            'kernel_ms_per_step': {n: float(v) for n, v in zip(names, kms)},
+            'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(names, kms)},
             'roofline': {'bound': 'hbm', 'kernel': 'k_' + names[dom], 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
-                         'launches': int(klaunch[dom])},
+                         'launches': int(klaunch[dom]), 'valu_util': pm.get('valu_util'),
+                         'valu_fp64_util': pm.get('valu_fp64_util'), 'lds_GBps': pm.get('lds_GBps'),
+                         'wave_cycles_waiting_frac': pm.get('wave_cycles_waiting_frac'),
+                         'counters_from': pm.get('source')},
         }
-        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
-            out['cpu_baseline'] = cpu_baseline(model, mine)
+        one = host_draws[-1][:1] if mine_n else None
+        if not args.no_single_solve and world == 1 and mine_n:
+            # single-solve latency (one draw): the "full backward-induction wall time" half of the metric
+            s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
+            s1.set_params(one)
+            s1.solve(raise_on_error=False)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                s1.solve(raise_on_error=False)
+            out['single_solve_ms'] = (time.perf_counter() - t1) / 3 * 1e3
+            s1.close()
+            if not args.no_extras:
+                # the same including the D2H copy of the full solution (SURVEY.md section 8d metric 2)
+                s2 = runtime.Solver(lib, desc, ndraw=1, keep_history=True)
+                s2.set_params(one)
+                s2.solve(raise_on_error=False)
+                t1 = time.perf_counter()
+                s2.solve(raise_on_error=False)
+                sol = s2.solution(0)
+                out['single_solve_plus_export_ms'] = (time.perf_counter() - t1) * 1e3
+                out['export_bytes'] = int(sol.len.sum()) * 24 + int(sol.thlen.sum()) * 16
+                s2.close()
+        if not args.no_extras and world == 1:
+            # measured streaming-copy rate of this box (read + write), the practical HBM ceiling beside the 8 TB/s spec
+            a = torch.empty(1 << 28, dtype=torch.float64, device='cuda')   # 2 GiB
+            b_ = torch.empty_like(a)
+            b_.copy_(a)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                b_.copy_(a)
+            torch.cuda.synchronize()
+            out['roofline']['hbm_copy_GBps_measured'] = 5 * 2 * a.numel() * 8 / (time.perf_counter() - t1) / 1e9
+            del a, b_
+        if not args.no_cpu_baseline and world == 1 and mine_n:   # reported baseline: rank 0 at N=1 only
+            out['cpu_baseline'] = cpu_baseline(args.workload, wl_kw, host_draws[-1])
             out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']
-            if single_ms:
-                out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / single_ms
+            if out.get('single_solve_ms'):
+                out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / out['single_solve_ms']
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -66,6 +66,7 @@ struct Batch {
     int *status;          // [ndraw] first error code
     int *where;           // [2*ndraw] (it, ist) of that error
     unsigned long long *evals;  // [ndraw]
+    unsigned long long *credited;  // [ndraw] part of evals that was accounted for without being executed (stage-0 fixed point)
     int *dbg;             // [16*ndraw] diagnostics of a tripped internal guard
     double *obj;          // [2*ndraw] staging of k_objective for the host-returning entry point
     unsigned long long *algbytes;  // [ndraw] compulsory table traffic: 24 B per next-period row read once per

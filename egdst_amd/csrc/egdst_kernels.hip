@@ -401,6 +401,8 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
         }
         __syncthreads();
     }
+    double fp_last = NAN, fp_M = NAN, kp_M = 0, kp_C = 0, kp_V = 0;  // previous visit of the resend branch; the point kept last
+    int fp_ncalls = -2, fp_ngen = -1, fp_np = 0, fp_nev = 0;
     int last_cnt = 0;  // evaluations of the most recent expectation
     int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
@@ -417,6 +419,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 // (:963-978) ends the stream.  Account for those calls instead of executing them.
                 const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still evaluate
                 nev += k * last_cnt;
+                if (lead && k > 0) atomicAdd(&b.credited[draw], (unsigned long long)k * (unsigned long long)last_cnt);
                 skipped = k + 1;  // (accounted for, not executed: no straggler work)
                 ncalls = b.g.ngridmax;
                 break;
@@ -457,6 +460,41 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 lim3 = ms_tr(&E, &cur, 0);
             }
             if (M <= a0 - 1 + EG_TOL) {  // c1<=0 signal: resend the prepared point (:1080-1099)
+                // Fixed point of the resend.  The generator signals "c1<=0" in band, by M = a0-1; when the re-sent guess
+                // itself returns an M below a0-1 (a re-based guess far below the credit limit), that genuine M is taken
+                // for the signal, the same guess is sent again, and -- the expectation being a pure function of the guess --
+                // every call from here to the runaway guard (:963-978) repeats the previous one: same guess, same M, the
+                // same kept point appended.  Seen on ~0.2 % of the C2 parameter draws, ~9000 sequential calls each.  Two
+                // consecutive visits with identical (guess, returned M) prove it; the remaining calls are then accounted
+                // for (points written, evaluations credited) instead of executed, exactly as the reference would end.
+                if (last == fp_last && M == fp_M && ncalls == fp_ncalls + 1 && ngenerated == fp_ngen) {
+                    const int dnp = np - fp_np, dnev = nev - fp_nev;
+                    const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still run before the guard ends the stream
+                    if (k > 0 && dnp >= 0 && dnp <= 1) {
+                        if (dnp == 1) {
+                            if (np + k - 1 >= b.g.ngridmax - 1) {  // (:662) the repeats fill the grid first
+                                if (lead) eg_fail(b, draw, it, ist, 13);
+                                return;
+                            }
+                            if (np + k > b.g.Cp) {
+                                if (lead) eg_fail(b, draw, it, ist, EGDST_E_CAPACITY);
+                                return;
+                            }
+                            for (int q = threadIdx.x; q < k; q += NW * WAVE) {
+                                b.cM[co + np + q] = kp_M;
+                                b.cC[co + np + q] = kp_C;
+                                b.cV[co + np + q] = kp_V;
+                            }
+                            np += k;
+                        }
+                        nev += k * dnev;
+                        if (lead && dnev > 0) atomicAdd(&b.credited[draw], (unsigned long long)k * (unsigned long long)dnev);
+                        skipped += k + 1;
+                        ncalls = b.g.ngridmax;
+                        break;
+                    }
+                }
+                fp_last = last, fp_M = M, fp_ncalls = ncalls, fp_ngen = ngenerated, fp_np = np, fp_nev = nev;
                 ncalls += 1;
                 keep = 1;
                 aa = (a0 - baseM) / (a0 - baseA);
@@ -673,13 +711,15 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 if (lead) eg_fail(b, draw, it, ist, EGDST_E_CAPACITY);
                 return;
             }
+            kp_M = M;
+            kp_C = M - last;
+            kp_V = ms_utility(&E, &cur, kp_C) + ms_discount(&E, &cur) * evf;
             if (lead) {
-                const double c = M - last;
-                b.cM[co + np] = M;
-                b.cC[co + np] = c;
-                b.cV[co + np] = ms_utility(&E, &cur, c) + ms_discount(&E, &cur) * evf;
+                b.cM[co + np] = kp_M;
+                b.cC[co + np] = kp_C;
+                b.cV[co + np] = kp_V;
             }
-            np += 1;  // full == 0: at most one kept point can precede the grid stage
+            np += 1;  // full == 0: normally at most one kept point precedes the grid stage
         }
     }
 #ifdef EGDST_EMU

@@ -32,7 +32,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
                'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments',
-               'egdst_get_checksums', 'egdst_math_eval']
+               'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -80,6 +80,7 @@ class ModelLibrary:
         L.egdst_solve.argtypes = [C.c_void_p]
         L.egdst_get_status.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_evals.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.egdst_get_evals_credited.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.egdst_cell_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_cell_M.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.egdst_get_cell_D.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -288,6 +289,15 @@ class Solver:
             per[self._redo] = self._exact.evals()[1]
             return int(per.sum()), per
         return int(tot.value), per
+
+    def evals_credited(self):
+        """per-draw evaluations that were accounted for without being executed (egdst_get_evals_credited)"""
+        tot = C.c_longlong(0)
+        per = np.zeros(self.ndraw, dtype=np.int64)
+        self.lib.check(self.lib.lib.egdst_get_evals_credited(self.h, C.byref(tot), per.ctypes.data_as(C.POINTER(C.c_longlong))))
+        if len(self._redo):
+            per[self._redo] = self._exact.evals_credited()
+        return per
 
     def objective(self):
         """[ndraw, 2] host array of the objective contributions (egdst_objective_dev), NaN for failed draws."""

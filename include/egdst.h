@@ -128,6 +128,10 @@ int egdst_get_status(egdst_handle *h, int *status /* [ndraw] */, int *where /* [
 
 /* EGM evaluations the reference would have executed (body at egdst_solver.c:548-570), summed over draws. */
 int egdst_get_evals(egdst_handle *h, long long *total, long long *per_draw /* [ndraw] or NULL */);
+/* The part of those counts that was accounted for WITHOUT being executed: when the guess generator's first stage gets
+ * M = +inf back for A = mmax it asks for mmax again until its runaway guard (egdst_solver.c:963-978); the expectation is a
+ * pure function of the guess, so the device executes it once and credits the repeats.  Throughput figures subtract this. */
+int egdst_get_evals_credited(egdst_handle *h, long long *total, long long *per_draw /* [ndraw] or NULL */);
 
 /* Cell export in the reference's wire layout (saveoutput, egdst_solver.c:917-952):
  *   M cell: (len x 4) column-major [M C A V], row 0 = (a0, 0, a0, evf(a0));  D cell: (thlen x 2) [D TH].

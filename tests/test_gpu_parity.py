@@ -224,8 +224,10 @@ def test_draws_with_many_monotone_pieces_bit_exact():
 
 
 def test_history_based_schedule_does_not_change_results():
-    """After a solve the handle moves draws with degenerate guess streams to lanes of their own (egdst_set_adaptive);
-    the next solves must give the same per-draw status, evaluation counts and objective values."""
+    """After a solve the handle moves draws whose guess streams re-based many times to lanes of their own
+    (egdst_set_adaptive); solves with and without it must give the same per-draw status, evaluation counts and objective
+    values.  (The draws that used to dominate -- the resend fixed point, ~9000 sequential calls -- are fast-forwarded
+    since round 2 and no longer register as work: their credited evaluations are checked instead.)"""
     m, gen = workloads.c2()
     P = gen(1024)[[0, 771, 3, 982, 5, 7, 11, 13]]
     lib = build.build_model(m)
@@ -234,9 +236,10 @@ def test_history_based_schedule_does_not_change_results():
     s.set_params(P)
     s.solve(raise_on_error=False)
     first = (s.status()[0].copy(), s.evals()[1].copy(), s.objective().copy())
-    assert s.work()[1] > 1000 and s.work()[3] > 1000          # the two degenerate draws were noticed
-    groups, lanes, nstrag = s.schedule()
-    assert nstrag == 2
+    cred = s.evals_credited()
+    assert cred[1] > 50000 and cred[3] > 50000 and cred[0] == 0          # the two degenerate draws were fast-forwarded
+    assert first[0][1] == 15 and first[0][3] == 15 and first[0][0] == 0
+    assert s.work()[1] < 1000 and s.work()[3] < 1000
     for _ in range(2):
         s.solve(raise_on_error=False)
         assert np.array_equal(s.status()[0], first[0]) and np.array_equal(s.evals()[1], first[1])
