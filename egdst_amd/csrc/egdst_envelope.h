@@ -53,8 +53,26 @@ template <bool L> struct EnvCtxT {
     int pm;         // function that is currently the max ((int)oix[oj-1])
     int ci;         // the reference's `ci` (persists across iterations)
     int *dbg;       // [16] diagnostics of a tripped guard
+    double *klog;   // kink log of this cell (the gateway's dbgout, egdst_solver.c:1866-1879): 4 doubles per recorded kink
+    int *kcnt;      // -- (choice whose secondary envelope runs or -1, threshold, consumption left, right); nullptr: off
+    int kcap;
     int err;
 };
+
+// one row of the solver gateway's third output (lane 0 of the walking wave calls this)
+template <bool L> static __device__ __forceinline__ void env_log_kink(EnvCtxT<L> &e, double x, double pol0, double pol1)
+{
+    if (!e.klog) return;
+    const int n = *e.kcnt;
+    if (n < e.kcap) {
+        double *o = e.klog + 4 * (size_t)n;
+        o[0] = (double)e.sec_id;  // (-1 in the primary envelope: dbgoutd, :718,804)
+        o[1] = x;
+        o[2] = pol0;
+        o[3] = pol1;
+    }
+    *e.kcnt = n + 1;
+}
 
 template <bool L> static __device__ __forceinline__ double env_evf(const EnvCtxT<L> &e, int f)
 {
@@ -250,6 +268,7 @@ template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L>
         e.og[e.oi] = x;
         e.ov[e.oi] = top;
         e.oc[e.oi] = (pol0 + pol1) / 2;
+        env_log_kink(e, x, pol0, pol1);
         e.oth[e.oj] = x;
         e.oix[e.oj] = nwi;
         e.pm = nwi;
@@ -572,6 +591,7 @@ template <bool L> static __device__ __forceinline__ void env_crossing_wave(EnvCt
             e.og[e.oi] = x;
             e.ov[e.oi] = top;
             e.oc[e.oi] = (pol0 + pol1) / 2;
+            env_log_kink(e, x, pol0, pol1);
             e.oth[e.oj] = x;
             e.oix[e.oj] = nwi;
         }

@@ -1471,6 +1471,9 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
     const eg_ldsd *evfa0;
     eg_ldsi *stack;
     int *dbg;
+    double *klog;  // kink log of the cell (dbgout), or nullptr
+    int *kcnt;
+    int kcap;
     double *og, *ov, *oc, *oth, *oix;
 };
 
@@ -1513,6 +1516,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.cap = j.cap;
     e.npts = j.npts;
     e.dbg = j.dbg;
+    e.klog = j.klog;
+    e.kcnt = j.kcnt;
+    e.kcap = j.kcap;
     e.err = 0;
     e.bound = 0;
     e.ci = 0;
@@ -1650,6 +1656,13 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     job.evfa0 = (const eg_ldsd *)s_evfa0;
     job.stack = (eg_ldsi *)s_stack;
     job.dbg = b.dbg + 16 * draw;
+    job.klog = nullptr, job.kcnt = nullptr, job.kcap = b.kcap;
+    if (b.klog) {  // third output of the solver gateway requested (egdst_set_dbgout): this cell's slice of the log
+        const size_t kc = ((size_t)it * b.g.ndraw + draw) * MS_NST + ist;
+        job.klog = b.klog + kc * 4 * (size_t)b.kcap;
+        job.kcnt = b.kcnt + kc;
+        if (tid == 0) *job.kcnt = 0;
+    }
 
 #ifdef EGDST_STAMPS  // diagnostic build: where does a workgroup spend its time (wall_clock64 ticks of 10 ns)
 #define STAMP(k)                                                                                   \
@@ -2214,20 +2227,37 @@ __global__ void k_env1_d(Batch b, int it, int ncells)
 // ---------------------------------------------------------------------------------------------
 // Forward simulation, one lane per agent (egdst_simulator.c:204-383, policy :145-199, output :122-143).
 struct SimArgs {
-    int draw, nsim, rndtype, nout;
+    int draw, nsim, rndtype, nout;   // first draw of the launch (blockIdx.y counts on from it)
+    int batch;                 // 1: several draws per launch, failed draws are skipped (their moments are NaN)
     const double *init;        // [nsim x 2] column-major
-    const double *randstream;  // uniforms
-    double *sims;              // [nout x nt x nsim]
+    const double *randstream;  // uniforms, or nullptr: generated from `seed` (eg_uniform)
+    unsigned long long seed;
+    double *sims;              // [draws of the launch][nout x nt x nsim]
     int *err;
 };
+
+// The counter-based uniform generator of the batched simulation (include/egdst.h: egdst_uniform is the same on the
+// host): number k of stream `seed` is the splitmix64 output for the state seed + (k+1)*golden, top 53 bits.
+static __host__ __device__ __forceinline__ double eg_uniform(unsigned long long seed, unsigned long long k)
+{
+    unsigned long long z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1p-53;
+}
 
 __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
 {
     const int isim = blockIdx.x * GRID_BS + threadIdx.x;
     if (isim >= a.nsim) return;
-    const int nt = b.g.nt, draw = a.draw;
+    const int nt = b.g.nt, draw = a.draw + (int)blockIdx.y;
+    if (a.batch && b.status[draw]) return;  // (a failed draw has no complete solution: its paths stay NaN)
+    a.sims += (size_t)blockIdx.y * a.nout * nt * a.nsim;
     ms_env E = eg_env(b, draw);
-    const double *rs = a.rndtype == 1 ? a.randstream : a.randstream + 4LL * nt * isim;
+    const unsigned long long rbase = a.rndtype == 1 ? 0ull : 4ull * (unsigned long long)nt * (unsigned long long)isim;
+    const double *rs = a.randstream ? a.randstream + rbase : nullptr;
+#define EG_RS(k) (rs ? rs[k] : eg_uniform(a.seed, rbase + (unsigned long long)(k)))
     const int ist0 = (int)a.init[isim] - 1;
     const double m0 = a.init[a.nsim + isim];
     if (ist0 < 0 || ist0 >= MS_NST) return;
@@ -2251,8 +2281,9 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
             np_.cash = 0;
             np_.shock = 0;
             np_.savings = cp.savings;
-            double r0 = rs[irnd++];
-            const double r1 = rs[irnd++], r2 = rs[irnd++];
+            double r0 = EG_RS(irnd);
+            const double r1 = EG_RS(irnd + 1), r2 = EG_RS(irnd + 2);
+            irnd += 3;
             if (r2 > ms_survival(&E, &cp)) return;  // death: remaining periods stay NaN
             double pr = 0;
             for (np_.ist = 0; np_.ist < MS_NST; np_.ist++) {
@@ -2417,6 +2448,9 @@ __global__ void __launch_bounds__(MOM_BS) k_moments(const double *sims, int nsim
     __shared__ double ssum[MOM_BS];
     __shared__ int scnt[MOM_BS];
     const int cell = blockIdx.x, tid = threadIdx.x;
+    sims += (size_t)blockIdx.y * ncell * nsim;   // (one set of paths, means and counts per draw of the launch)
+    means += (size_t)blockIdx.y * ncell;
+    counts += (size_t)blockIdx.y * ncell;
     double acc = 0;
     int cnt = 0;
     for (int i = tid; i < nsim; i += MOM_BS) {
@@ -2436,10 +2470,32 @@ __global__ void __launch_bounds__(MOM_BS) k_moments(const double *sims, int nsim
     }
 }
 
-__global__ void k_fill_nan(double *p, size_t n)
+// Distance of one draw's simulated moments to the targets: sum over the cells with a non-zero weight of
+// weight * (mean - target)^2, added in cell order by one thread per draw (deterministic); NaN if a weighted cell is empty.
+__global__ void k_moment_objective(const double *means, const int *counts, int ncell, const double *target, const double *weight,
+                                   int ndraw, double *obj)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= ndraw) return;
+    const double *m = means + (size_t)d * ncell;
+    const int *c = counts + (size_t)d * ncell;
+    double acc = 0;
+    for (int k = 0; k < ncell; k++) {
+        if (weight[k] == 0.0) continue;
+        if (c[k] == 0) {
+            acc = NAN;
+            break;
+        }
+        const double e = m[k] - target[k];
+        acc += weight[k] * e * e;
+    }
+    obj[d] = acc;
+}
+
+__global__ void k_fill_nan(double *p, size_t n, size_t per_draw)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (i == 0) ? 0.0 : NAN;  // NaN fill starts at element 1 (egdst_simulator.c:105)
+    if (i < n) p[i] = (i % per_draw == 0) ? 0.0 : NAN;  // NaN fill starts at element 1 of a draw's output (egdst_simulator.c:105)
 }
 
 // Per-draw objective contribution for an estimation loop (new surface): the value and the

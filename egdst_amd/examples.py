@@ -245,6 +245,46 @@ def retirement8(T=100, ngridm=32768, ny=15, mmax=50.0, duw=0.5, wage=1.05, sigma
     return m
 
 
+
+def cake_normal(**over):
+    """egdst_examples/model_cake1.m:6-40 forms (log utility, one state, one decision, discount 1) with the shock switched
+    on: an ADDITIVE NORMAL income (shock type 'normal': rescale() = mu + x*sigma, egdst_lib.c:84-100) -- the DISTRIB=2
+    branch of the solver and the simulator, which none of the shipped scripts reaches with sigma > 0."""
+    m = egdstmodel('cakenormal')
+    m.t0 = 1
+    m.T = 25
+    m.mmax = 10
+    m.ngridmax = 1000
+    m.ngridm = 100
+    m.nthrhmax = 10
+    m.ny = 6
+    m.s = ('Singleton state', [0, 'dummy state'])
+    m.trpr = ('true', [[1]])
+    m.feasible = ('defaultfeasible', True)
+    m.d = ('Dummy decision', [0, 'dummy decision'])
+    m.choiceset = ('defaultallow', True)
+    m.u = ('utility', 'log(consumption)')
+    m.u = ('marginal', '1/consumption')
+    m.u = ('marginalinverse', '1/mutility')
+    m.u = ('extrap', 'log(x)')
+    m.budget = ('cashinhand', 'savings+shock')
+    m.budget = ('marginal', '1')
+    m.discount = '0.97'
+    m.a0 = 0
+    m.shock = 'normal'
+    m.shock = ('sigma', '0.15')
+    m.shock = ('mu', '0.6')
+    return _apply(m, over)
+
+
+def retirement_mortal(**over):
+    """model_retirement2.m forms with a survival probability below one that falls with age (egdstmodel.m:95-104): the
+    simulator's death draw (egdst_simulator.c:265) -- agents leave the panel, the remaining periods stay NaN."""
+    m = _retirement('retiremortal', '0.25', '-0.5*sigma*sigma')
+    m.survival = '1.0-0.004*it'
+    return _apply(m, over)
+
+
 REGISTRY = {'deaton1': deaton1, 'deaton2': deaton2, 'deaton_sig': deaton_sig, 'retirement1': retirement1,
             'retirement2': retirement2, 'retirement_sig': retirement_sig, 'occ3': occ3, 'model2': model2,
-            'retirement8': retirement8}
+            'retirement8': retirement8, 'cake_normal': cake_normal, 'retirement_mortal': retirement_mortal}

@@ -579,15 +579,17 @@ class egdstmodel:  # noqa: N801  (reference class name)
         self.needtocompile = False
         return self._lib
 
-    def solve(self, keep_on_device=False):
-        """``[M,D]=egdst_solver(model)`` (egdstmodel.m:1141-1178) through the C-ABI."""
+    def solve(self, keep_on_device=False, dbgout=False):
+        """``[M,D,dbgout]=egdst_solver(model)`` (egdstmodel.m:1141-1178) through the C-ABI.  The class drops the third
+        output (egdstmodel.m:1170); dbgout=True keeps it in ``self.dbgout`` ([nt*nst*nd*2*nt, 7])."""
         if self.needtocompile or self._lib is None:
             raise EgdstError('The model needs to be compiled first!\nRun <model>.compile')
         from . import runtime
         import time
         t = time.perf_counter()
-        sol = runtime.solve_model(self)
+        sol = runtime.solve_model(self, dbgout=dbgout)
         self.lastrun_solver = time.perf_counter() - t
+        self.dbgout = getattr(sol, 'dbgout', None)
         self._solution = sol
         self.M, self.D = sol.cells()
         return sol

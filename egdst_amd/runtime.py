@@ -32,7 +32,8 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
                'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments',
-               'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited']
+               'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited', 'egdst_simulate_batch_moments',
+               'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -81,6 +82,12 @@ class ModelLibrary:
         L.egdst_get_status.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_evals.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.egdst_get_evals_credited.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.egdst_simulate_batch_moments.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_longlong, C.c_ulonglong,
+                                                   C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.egdst_uniform.restype = C.c_double
+        L.egdst_uniform.argtypes = [C.c_ulonglong, C.c_ulonglong]
+        L.egdst_set_dbgout.argtypes = [C.c_void_p, C.c_int]
+        L.egdst_get_dbgout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.egdst_cell_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.egdst_get_cell_M.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.egdst_get_cell_D.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -322,6 +329,19 @@ class Solver:
         sol.nevals = int(self.evals()[1][draw])
         return sol
 
+    def set_dbgout(self, on=True):
+        """keep the kink log of the next solves (third output of the solver gateway)"""
+        self.lib.check(self.lib.lib.egdst_set_dbgout(self.h, int(bool(on))))
+
+    def dbgout(self, draw=0):
+        """(matrix [cap, 7] as the gateway returns it, number of recorded rows)"""
+        info = self.lib.info
+        cap = self.nt * info.nst * info.nd * 2 * self.nt
+        out = np.zeros((cap, 7), order='F')
+        n = C.c_int(0)
+        self.lib.check(self.lib.lib.egdst_get_dbgout(self.h, draw, _dp(out), C.byref(n)))
+        return out, n.value
+
     def checksums(self, draw=0):
         """[nt, nst, 5] uint64 checksums of the draw's cells (columns M, C, V, TH, D), computed on the device."""
         if len(self._redo) and self._route(draw)[0] is not self:
@@ -397,6 +417,32 @@ class Solver:
                                                            _dp(means), _ip(counts)))
         return means, counts
 
+    def simulate_batch_moments(self, init, seed=0, rndtype=0, target=None, weight=None, randstream_dev=None, nrand=0,
+                               means_dev=None, counts_dev=None, obj_dev=None):
+        """egdst_simulate_batch_moments: all draws of the handle, common random numbers; the *_dev arguments are device
+        pointers (ints).  With no device pointers given, returns (means [ndraw, nt, nout], counts, objective [ndraw]) through
+        torch tensors allocated here."""
+        init = np.asfortranarray(np.atleast_2d(np.asarray(init, dtype=np.float64)))
+        info = self.lib.info
+        nout = 11 + info.nnst + info.nnd + info.neq
+        ncell = nout * self.nt
+        t = np.ascontiguousarray(np.zeros(ncell) if target is None else target, dtype=np.float64).reshape(-1)
+        w = np.ascontiguousarray(np.zeros(ncell) if weight is None else weight, dtype=np.float64).reshape(-1)
+        own = means_dev is None and counts_dev is None and obj_dev is None
+        if own:
+            import torch
+            tm = torch.zeros(self.ndraw, self.nt, nout, dtype=torch.float64, device='cuda')
+            tc = torch.zeros(self.ndraw, self.nt, nout, dtype=torch.int32, device='cuda')
+            to = torch.zeros(self.ndraw, dtype=torch.float64, device='cuda')
+            means_dev, counts_dev, obj_dev = tm.data_ptr(), tc.data_ptr(), to.data_ptr()
+        self.lib.check(self.lib.lib.egdst_simulate_batch_moments(
+            self.h, _dp(init), init.shape[0], C.c_void_p(randstream_dev) if randstream_dev else None, int(nrand), int(seed),
+            int(rndtype), _dp(t), _dp(w), C.c_void_p(means_dev) if means_dev else None,
+            C.c_void_p(counts_dev) if counts_dev else None, C.c_void_p(obj_dev) if obj_dev else None))
+        if own:
+            return tm.cpu().numpy(), tc.cpu().numpy(), to.cpu().numpy()
+        return None
+
     def call(self, sw, args, draw=0):
         """egdst_call gateway (egdst_call.c:17-164): sw 1 utility, 2 marginal utility, 3 discount, 4 budget, 5 marginal
         budget, 6 value function; args [narg x ncol] with 1-based it/ist/id as in MATLAB.  Returns [narg]."""
@@ -423,7 +469,7 @@ class Solver:
         return sims
 
 
-def solve_model(model):
+def solve_model(model, dbgout=False):
     """model.solve(): one draw with the model's current parameters, history kept for sim/export."""
     desc = model.descriptor()
     if model.__dict__.get('_solver') is not None:
@@ -431,8 +477,12 @@ def solve_model(model):
     s = Solver(model._lib, desc, ndraw=1, keep_history=True)
     model.__dict__['_solver'] = s
     s.set_params(model.param_vector())
+    if dbgout:
+        s.set_dbgout(True)
     rc = s.solve(raise_on_error=False)
     sol = s.solution(0)
+    if dbgout:
+        sol.dbgout, sol.dbgn = s.dbgout(0)
     if rc:
         # the reference warns and returns the partially filled cells (egdst_solver.c:237)
         import warnings

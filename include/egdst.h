@@ -156,6 +156,22 @@ int egdst_simulate(egdst_handle *h, int draw, const double *init, int nsim, cons
 int egdst_simulate_moments(egdst_handle *h, int draw, const double *init, int nsim, const double *randstream,
                            long long nrand, int rndtype, double *means /* [nout*nt] */, int *counts /* [nout*nt] */);
 
+/* The estimation step on the device: EVERY draw of the handle is simulated with the same nsim agents
+ * (init as in egdst_simulate) and the same uniforms -- common random numbers -- and per draw only moments and an
+ * objective leave the kernels:
+ *   means_dev [ndraw][nout*nt], counts_dev [ndraw][nout*nt]   as egdst_simulate_moments, DEVICE buffers (may be NULL)
+ *   obj_dev   [ndraw]   sum over the cells with weight != 0 of weight[k] * (mean[k] - target[k])^2, k = col + nout*it
+ *                       (target, weight: host, [nout*nt]); NaN for a draw that failed to solve or has an empty weighted
+ *                       cell.  DEVICE buffer (e.g. a torch tensor): it is what the cross-GPU reduce (RCCL) takes.
+ * Uniforms: randstream_dev (device, layout and length rules of egdst_simulate) or NULL: generated on the device by the
+ * counter-based generator egdst_uniform(seed, k) below, k the index a randstream would have.  Requires keep_history=1. */
+int egdst_simulate_batch_moments(egdst_handle *h, const double *init, int nsim, const double *randstream_dev,
+                                 long long nrand, unsigned long long seed, int rndtype, const double *target,
+                                 const double *weight, double *means_dev, int *counts_dev, double *obj_dev);
+/* Uniform number k of stream `seed` (host replay of the device generator): with z = seed + (k+1)*0x9E3779B97F4A7C15,
+ * z = (z ^ z>>30)*0xBF58476D1CE4E5B9, z = (z ^ z>>27)*0x94D049BB133111EB, z ^= z>>31 (splitmix64): (z >> 11) * 2^-53. */
+double egdst_uniform(unsigned long long seed, unsigned long long k);
+
 /* Model-function accessor behind egdstmodel.call (egdst_call.c:17-164; egdstmodel.m:1181-1207).  sw: 1 utility
  * (it, ist, id, consumption), 2 marginal utility (same), 3 discount (it, ist), 4 budget (it, ist, id, savings, ist1,
  * shock), 5 marginal budget (same), 6 value function from the solved tables (it, ist, cash).  args: host, [narg x ncol]
@@ -180,6 +196,16 @@ int egdst_get_profile(egdst_handle *h, double *ms /* [3] */, int *launches /* [3
 
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);
+
+/* Third output of the solver gateway, [M,D,dbgout] = egdst_solver(model) (egdst_solver.c:178-181, filled in thresholds()
+ * :1866-1879, DEBUGOUT is always on in the reference): one row per kink the secondary and primary envelopes record, in the
+ * order they are recorded -- it, ist, the choice whose secondary envelope it is (-1: primary), the threshold, consumption
+ * left and right of it (-.9999 where it is the zero-consumption marker), |right - left|.  egdst_set_dbgout(h, 1) before
+ * the solve makes the kernels keep the log (device memory: nt*ndraw*nst*min((nd+1)*nthrhmax, cap)*32 B, so meant for the
+ * single-draw handle of the gateway); egdst_get_dbgout copies one draw's rows into out [cap x 7] column-major with
+ * cap = nt*nst*nd*2*nt, zero rows after the *nrows recorded ones, rows beyond cap dropped, as the reference does. */
+int egdst_set_dbgout(egdst_handle *h, int on);
+int egdst_get_dbgout(egdst_handle *h, int draw, double *out /* [nt*nst*nd*2*nt * 7] */, int *nrows);
 
 /* Checksums of one draw's solution, computed on the device: out[(it*nst+ist)*5 + k] = wrapping 64-bit sum of the bit
  * patterns of column k in {M, C, V} over the cell's rows and of {TH, D} over its thresholds.  Lets a caller (and the

@@ -57,6 +57,12 @@ typedef struct {
     int *thlen;        /* [nt*nst] */
     long long nevals;  /* executions of the body at egdst_solver.c:548-570 */
     char err[300];
+    /* third output of the solver gateway (DEBUGOUT, egdst_solver.c:39,178-181,1866-1879): one row per kink the envelopes
+       record, in the order they are recorded -- columns it, ist, choice whose secondary envelope it is (-1: primary),
+       threshold, consumption left and right of it (-.9999 for the zero-consumption marker), |jump|.  Column-major
+       [dbgcap x 7], dbgcap = nt*nst*nd*2*nt as the gateway sizes it; rows beyond the capacity are dropped.  NULL: off. */
+    double *dbgout;
+    int dbgcap, dbgn;
 } orc_solution;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -171,6 +177,7 @@ typedef struct {
     int nt, stride; /* stride = ngridmax+1 */
     double *qw, *qz; /* weights, standard-normal nodes */
     char *err;
+    int dbg_id; /* dbgoutd of the reference: the choice whose secondary envelope runs, -1 in the primary one (:718,804) */
 } ctx_t;
 
 /* next-period table accessors: slot of (it+1, ist1) */
@@ -539,6 +546,18 @@ static void crossing(env_t *e, int pri, int nwi, int mode)
     pol[0] = policy_val(e, pri, x);
     pol[1] = policy_val(e, nwi, x);
     e->oc[e->oi] = (pol[0] + pol[1]) / 2;
+    if (c->sol->dbgout && c->sol->dbgn < c->sol->dbgcap) { /* :1866-1879 */
+        double *o = c->sol->dbgout + c->sol->dbgn;
+        const int n = c->sol->dbgcap;
+        o[0] = e->it;
+        o[n] = e->ist;
+        o[2 * n] = c->dbg_id;
+        o[3 * n] = x;
+        o[4 * n] = (pol[0] == ZEROC) ? -.9999 : pol[0];
+        o[5 * n] = (pol[1] == ZEROC) ? -.9999 : pol[1];
+        o[6 * n] = fabs(pol[1] - pol[0]);
+        c->sol->dbgn++;
+    }
     e->oth[e->oj] = x;
     e->oix[e->oj] = nwi;
     e->oi += 1;
@@ -776,6 +795,7 @@ static int secondary_envelope(ctx_t *c, const ms_pv *cur, pt_t *pts, int n, doub
     }
     if (nadd > 0) {
         double *o = calloc((size_t)5 * ngridmax, sizeof(double));
+        c->dbg_id = cur->id;
         upper_envelope(c, cur->it, cur->ist, seg + 1, total, pts, evf, o, o + ngridmax, o + 2 * ngridmax,
                        o + 3 * ngridmax, o + 4 * ngridmax, &nout, &mout);
         if (!c->err[0] && nout >= ngridmax) fail(c, "Not enough space for endogenous grid in envelop2()");
@@ -897,6 +917,7 @@ static void solve_state(ctx_t *c, int it, int ist)
         fail(c, "All of the choices lead to -inf value functions for all values of money-at-hand!");
         goto out;
     }
+    c->dbg_id = -1;
     upper_envelope(c, it, ist, MS_ND, nall, pts, evfa0, oM + 1, oV + 1, oC + 1, TAB_TH(c, it, ist), TAB_D(c, it, ist),
                    &outn, &outm);
     if (c->err[0]) goto out;
@@ -926,6 +947,7 @@ int egdst_oracle_solve(const orc_desc *d, const double *par, orc_solution *sol)
     c.err = sol->err;
     sol->err[0] = 0;
     sol->nevals = 0;
+    sol->dbgn = 0;
     c.E.t0 = d->t0;
     c.E.T = d->T;
     c.E.ngridm = d->ngridm;

@@ -22,7 +22,8 @@ class OrcDesc(C.Structure):
 class OrcSolution(C.Structure):
     _fields_ = [('M', C.POINTER(C.c_double)), ('C', C.POINTER(C.c_double)), ('V', C.POINTER(C.c_double)),
                 ('D', C.POINTER(C.c_double)), ('TH', C.POINTER(C.c_double)), ('len', C.POINTER(C.c_int)),
-                ('thlen', C.POINTER(C.c_int)), ('nevals', C.c_longlong), ('err', C.c_char * 300)]
+                ('thlen', C.POINTER(C.c_int)), ('nevals', C.c_longlong), ('err', C.c_char * 300),
+                ('dbgout', C.POINTER(C.c_double)), ('dbgcap', C.c_int), ('dbgn', C.c_int)]
 
 
 def _dp(a):
@@ -84,14 +85,21 @@ class Oracle:
         return OrcDesc(d['t0'], d['T'], d['ngridm'], d['ngridmax'], d['nthrhmax'], d['ny'], d['mmax'], d['a0'],
                        _dp(self._quad)), d
 
-    def solve(self, params=None):
+    def solve(self, params=None, dbgout=False):
+        """dbgout=True: also the third output of the solver gateway, sol.dbgout [cap x 7] (zero rows past sol.dbgn)."""
         desc, d = self._desc()
         nt = d['T'] - d['t0'] + 1
         sol = OracleSolution(nt, self.nst, d['ngridmax'], d['nthrhmax'])
         par = np.ascontiguousarray(self.model.param_vector() if params is None else params, dtype=np.float64)
         cs = OrcSolution(_dp(sol.M), _dp(sol.C), _dp(sol.V), _dp(sol.D), _dp(sol.TH),
                          sol.len.ctypes.data_as(C.POINTER(C.c_int)), sol.thlen.ctypes.data_as(C.POINTER(C.c_int)))
+        if dbgout:
+            cap = nt * self.nst * self.nd * 2 * nt                      # egdst_solver.c:178
+            dbg = np.zeros((cap, 7), order='F')
+            cs.dbgout, cs.dbgcap = _dp(dbg), cap
         rc = self.lib.egdst_oracle_solve(C.byref(desc), _dp(par), C.byref(cs))
+        if dbgout:
+            sol.dbgout, sol.dbgn = dbg, int(cs.dbgn)
         sol.nevals = int(cs.nevals)
         sol.err = cs.err.decode(errors='replace')
         sol.rc = rc

@@ -17,7 +17,7 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, 'include', 'egdst.h')).read()
-    declared = set(re.findall(r'^(?:const char \*|int )(egdst_[A-Za-z_]+)\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^(?:const char \*|int |double )(egdst_[A-Za-z_]+)\(', hdr, flags=re.M))
     assert declared == set(runtime.ABI_SYMBOLS), declared ^ set(runtime.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(lib.lib, s)

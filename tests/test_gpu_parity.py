@@ -375,3 +375,82 @@ def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
     ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
     assert ok, rep
     assert sol.nevals == ref.nevals
+
+
+@pytest.mark.parametrize('name', ['cake_normal', 'retirement_mortal'])
+@pytest.mark.parametrize('rndtype', [0, 1])
+def test_normal_shocks_mortality_and_shared_streams(name, rndtype):
+    """The branches no shipped script reaches: additive normal shocks (DISTRIB=2: rescale = mu + x*sigma, egdst_lib.c:84-100;
+    model_cake1.m forms with sigma > 0), a survival probability below one (death draw, egdst_simulator.c:265: the rest of
+    the path stays NaN), and rndtype=1 (every agent re-uses the head of the stream, egdst_simulator.c:109-114).
+    Solution and simulated panel bit for bit against the oracle."""
+    m = examples.REGISTRY[name]()
+    s = gpu_solve(m)
+    orc = Oracle(m)
+    ref = orc.solve()
+    sol = s.solution(0)
+    assert ref.rc == 0 and sol.status == 0
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    assert sol.nevals == ref.nevals
+    nsim = 300
+    rng = np.random.default_rng(4)
+    init = np.column_stack([np.ones(nsim), rng.uniform(m.a0, m.mmax, nsim)])
+    rs = rng.random(4 * m.nt * (1 if rndtype == 1 else nsim))
+    sims, rsims = s.simulate(init, rs, rndtype=rndtype), orc.sim(ref, init, rs, rndtype=rndtype)
+    assert np.array_equal(sims, rsims, equal_nan=True)
+    alive = (~np.isnan(sims[:, :, 0])).sum(axis=0)
+    if name == 'retirement_mortal':
+        assert alive[0] == nsim and (alive[-1] < alive[0] if rndtype == 0 else alive[-1] in (0, nsim))  # shared stream: all die together
+    else:
+        assert np.all(alive == nsim)
+    if rndtype == 1:   # too short a stream is refused with the gateway's message (egdst_simulator.c:71-75)
+        with pytest.raises(runtime.EgdstRuntimeError) as e:
+            s.simulate(init, rs[:4 * m.nt - 1], rndtype=1)
+        assert e.value.code == 41
+
+
+@pytest.mark.parametrize('rndtype', [0, 1])
+def test_estimation_step_on_device(rndtype):
+    """egdst_simulate_batch_moments: every draw of a batch simulated on the device with generated uniforms
+    (common random numbers), moments reduced per draw, objective = weighted distance to target moments -- against the
+    oracle fed with the host replay of the same uniforms: counts exact, means 1e-13, objective 1e-11; a draw that fails to
+    solve has a NaN objective."""
+    import estimation_case
+    m, gen = workloads.c2(ngridm=300, T=30)
+    P = gen(1024)[[0, 1, 2, 3, 5, 8, 13, 771]]
+    s = gpu_solve(m, P)
+    rng = np.random.default_rng(5)
+    nsim = 2000
+    init = np.column_stack([np.ones(nsim), rng.uniform(m.a0 - 0.5, m.mmax + 0.5, nsim)])
+    bad = estimation_case.check(s, Oracle(m), P, init, seed=99 + rndtype, rndtype=rndtype, lib=s.lib)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('name', ['retirement2', 'occ3', 'retire8', 'model2', 'C2', 'occ3_n400'])
+def test_solver_gateway_third_output_dbgout(name):
+    """[M,D,dbgout] = egdst_solver(model): the kink log of thresholds() (egdst_solver.c:178-181,1866-1879) -- period,
+    state, choice of the secondary envelope or -1, threshold, consumption either side, jump -- row for row equal to the
+    oracle's, zero rows after the recorded ones, and the solve itself unchanged by the logging."""
+    m = (CASES.get(name) or SCALED[name])()
+    lib = build.build_model(m)
+    s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
+    s.set_dbgout(True)
+    s.set_params(m.param_vector()[None])
+    s.solve(raise_on_error=False)
+    ref = Oracle(m).solve(dbgout=True)
+    out, n = s.dbgout(0)
+    assert n == ref.dbgn and n > 0
+    assert out.shape == ref.dbgout.shape and np.array_equal(out, ref.dbgout)
+    assert np.all(out[n:] == 0)
+    ok, rep = compare(s.solution(0), ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    th = np.concatenate([ref.TH[it, ist, 1:ref.thlen[it, ist]] for it in range(ref.len.shape[0] - 1, -1, -1) for ist in range(ref.len.shape[1])])
+    assert np.array_equal(out[:n][out[:n, 2] == -1, 3], th)   # the primary rows are the thresholds of the D cells
+
+
+def test_class_surface_dbgout():
+    m = examples.retirement2()
+    m.compile()
+    m.solve(dbgout=True)
+    assert m.dbgout.shape == (m.nt * 1 * 2 * 2 * m.nt, 7) and m.dbgout[0, 0] == m.nt - 2 and m.dbgout[0, 2] == -1

@@ -159,3 +159,15 @@ print('moments ok', ok)
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'moments ok True' in r.stdout, r.stdout + r.stderr[-2000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+def test_estimation_step_kernels():
+    """egdst_simulate_batch_moments under ASan: batch simulation with device-generated uniforms (own and shared streams),
+    per-draw moments and the moment objective equal the oracle's on the host replay of the same uniforms."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_estimation.py')], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'estimation problems: 0' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
