@@ -86,15 +86,25 @@ class _Rewriter:
             if t == 'ist1':
                 need_next(t)
                 return 'next->ist'
+            # with continuous states the simulator evaluates the model functions BY VALUE (byval, egdst_lib.h:63,
+            # compile.m:26-34): states and decisions are then read from the period's own st[]/dc[] instead of the tables
+            byval = any(v.type == 'continuous' for v in m.s)
             mm = re.fullmatch(r'dc(\d+)', t)
             if mm and 1 <= int(mm.group(1)) <= m.nnd:
-                return 'ms_decisions[curr->id+%d*MS_ND]' % (int(mm.group(1)) - 1)
+                k = int(mm.group(1)) - 1
+                if byval:
+                    return '(curr->byval>0?curr->dc[%d]:ms_decisions[curr->id+%d*MS_ND])' % (k, k)
+                return 'ms_decisions[curr->id+%d*MS_ND]' % k
             mm = re.fullmatch(r'st(\d+)(n?)', t)
             if mm and 1 <= int(mm.group(1)) <= m.nnst:
                 k = int(mm.group(1)) - 1
                 if mm.group(2):
                     need_next(t)
+                    if byval:
+                        return '(next->byval>0?next->st[%d]:ms_states[next->ist+%d*MS_NST])' % (k, k)
                     return 'ms_states[next->ist+%d*MS_NST]' % k
+                if byval:
+                    return '(curr->byval>0?curr->st[%d]:ms_states[curr->ist+%d*MS_NST])' % (k, k)
                 return 'ms_states[curr->ist+%d*MS_NST]' % k
             if t in self.eqs:
                 if self.eqs[t].type == 'next':
@@ -245,7 +255,19 @@ def generate_modelspec(model):
         w('#define MS_%s (%s)' % (k, m.cflags[k]))
     w('#define MS_MAX(X,Y) (((X)>(Y))?(X):(Y))')
     w('#define MS_MIN(X,Y) (((X)<(Y))?(X):(Y))')
-    w('typedef struct ms_pv {int it; int ist; int id; double cash; double savings; double shock;} ms_pv;')
+    cont = [i for i, v in enumerate(m.s) if v.type == 'continuous']
+    w('#define MS_NCONT %d  /* continuous state variables (SURVEY 8f N4) */' % len(cont))
+    if cont:
+        # PeriodVars with the by-value fields of the simulator (compile.m:192); C++ gives byval its default, C code sets it
+        w('#ifdef __cplusplus')
+        w('struct ms_pv {int it; int ist; int id; double cash; double savings; double shock; int byval = 0; '
+          'double st[MS_NNST]; double dc[MS_NND];};')
+        w('#else')
+        w('typedef struct ms_pv {int it; int ist; int id; double cash; double savings; double shock; int byval; '
+          'double st[MS_NNST]; double dc[MS_NND];} ms_pv;')
+        w('#endif')
+    else:
+        w('typedef struct ms_pv {int it; int ist; int id; double cash; double savings; double shock;} ms_pv;')
     w('typedef struct ms_env {int t0; int T; int ngridm; int ngridmax; int nthrhmax; int ny; '
       'double mmax; double a0; const double* par;} ms_env;')
     # constant tables
@@ -257,6 +279,23 @@ def generate_modelspec(model):
     w('MS_TABLE double ms_states[%d] = {%s};' % (m.nst * m.nnst, ','.join(_fmt(v) for v in st.T.reshape(-1))))
     dc = np.asarray(m.decisions, dtype=float)
     w('MS_TABLE double ms_decisions[%d] = {%s};' % (m.nd * m.nnd, ','.join(_fmt(v) for v in dc.T.reshape(-1))))
+    w('MS_TABLE int ms_stcont[%d] = {%s};  /* 1: continuous */' % (max(m.nnst, 1), ','.join('1' if v.type == 'continuous' else '0' for v in m.s) or '0'))
+    for i in cont:
+        w('MS_TABLE double ms_stgrid%d[%d] = {%s};' % (i + 1, len(m.s[i].values), ','.join(_fmt(v) for v in m.s[i].values)))
+    if cont:
+        # bxsearch (egdst_lib.c:123-176, type 0): left index for interpolation with extrapolation on both sides
+        w('MS_FN int ms_bxsearch(double x, const double* g, int n) {')
+        w('  int lo = 1, hi = n - 2, mid;')
+        w('  if (x < g[1]) return 0;')
+        w('  if (x >= g[n-2]) return n - 2;')
+        w('  while (hi - lo > 1) { mid = (hi + lo) / 2; if (g[0] <= g[n-1] && g[mid] > x) hi = mid; else lo = mid; }')
+        w('  return lo;')
+        w('}')
+        w('MS_FN const double* ms_stgrid(int k) {')
+        for i in cont:
+            w('  if (k == %d) return ms_stgrid%d;' % (i, i + 1))
+        w('  return 0;')
+        w('}')
     for c in m.coef:
         # base-1 indexing kept by padding row/column 0 (compile.m:199-219); values printed %18.15f there
         r, cc = c.array.shape
@@ -316,29 +355,65 @@ def generate_modelspec(model):
                                   int(not m.feasible['defaultfeasible'])))
     w('  return res;')
     w('}')
-    # transition probabilities (compile.m:476-551); *err is raised on an incomplete case list
+    # transition probabilities (compile.m:476-551); *err is raised on an incomplete case list.  `all` (compile.m:482):
+    # 1 = the solver's call, continuous states contribute their interpolation weights; 0 = the simulator's call, discrete
+    # variables only.  Models without continuous states keep the four-argument form (ms_trpr_all is then ms_trpr).
+    def trpr_body(with_all):
+        w('  double res = 1.0;')
+        w('  int varindex, varindex1;')
+        if cont:
+            w('  double nval; (void)nval;')
+        for tr in m.trpr:
+            k = tr.varindex - 1
+            n = sizes[k]
+            is_cont = m.s[k].type == 'continuous'
+            w('  varindex = (curr->ist/%d)%%%d; varindex1 = (next->ist/%d)%%%d;' % (strides[k], n, strides[k], n))
+            first = True
+            for case in tr.cases:
+                w('  %sif (%s) {' % ('' if first else 'else ', rw.convert(case.condition, True, 'trpr condition')))
+                first = False
+                if not is_cont:
+                    w('    switch (varindex*%d+varindex1) {' % n)
+                    for i in range(n):
+                        for j in range(n):
+                            w('      case %d: res *= %s; break;' % (i * n + j, rw.convert(case.prob[i][j], True, 'trpr')))
+                    w('      default: break;')
+                    w('    }')
+                elif with_all:
+                    # deterministic motion rule: linear-interpolation weights of the two neighbouring grid points (:527-538)
+                    g = 'ms_stgrid%d' % (k + 1)
+                    w('    nval = %s;' % rw.convert(case.prob, True, 'motion rules', ('ist1',)))
+                    w('    varindex = ms_bxsearch(nval, %s, %d);' % (g, n))
+                    w('    if (varindex==varindex1) res *= (%s[varindex+1]-nval)/(%s[varindex+1]-%s[varindex]);' % (g, g, g))
+                    w('    else if (varindex+1==varindex1) res *= (nval-%s[varindex])/(%s[varindex+1]-%s[varindex]);' % (g, g, g))
+                    w('    else return 0.0;')
+                w('  }')
+            w('  else { *err = 1; return 0.0; }')
+            w('  if (res==0.0) return 0.0;')
+        w('  return res;')
+
     w('MS_FN double ms_trpr(%s, int* err) {' % C2)
-    w('  double res = 1.0;')
-    w('  int varindex, varindex1;')
-    for tr in m.trpr:
-        k = tr.varindex - 1
-        n = sizes[k]
-        w('  varindex = (curr->ist/%d)%%%d; varindex1 = (next->ist/%d)%%%d;' % (strides[k], n, strides[k], n))
-        first = True
-        for case in tr.cases:
-            w('  %sif (%s) {' % ('' if first else 'else ', rw.convert(case.condition, True, 'trpr condition')))
-            first = False
-            w('    switch (varindex*%d+varindex1) {' % n)
-            for i in range(n):
-                for j in range(n):
-                    w('      case %d: res *= %s; break;' % (i * n + j, rw.convert(case.prob[i][j], True, 'trpr')))
-            w('      default: break;')
-            w('    }')
-            w('  }')
-        w('  else { *err = 1; return 0.0; }')
-        w('  if (res==0.0) return 0.0;')
-    w('  return res;')
+    trpr_body(True)
     w('}')
+    if cont:
+        w('MS_FN double ms_trpr_discrete(%s, int* err) {  /* all == 0 */' % C2)
+        trpr_body(False)
+        w('}')
+        # exact next-period values of the continuous states (trpr_cont, compile.m:553-575)
+        w('MS_FN void ms_trpr_cont(const ms_env* E, const ms_pv* curr, ms_pv* next) {')
+        for tr in m.trpr:
+            k = tr.varindex - 1
+            if m.s[k].type != 'continuous':
+                continue
+            first = True
+            for case in tr.cases:
+                w('  %sif (%s) {' % ('' if first else 'else ', rw.convert(case.condition, True, 'trpr condition')))
+                first = False
+                w('    next->st[%d] = %s;' % (k, rw.convert(case.prob, True, 'motion rules')))
+                w('  }')
+        w('}')
+    else:
+        w('#define ms_trpr_discrete ms_trpr')
     # equations for the simulator output (compile.m:629-649)
     w('MS_FN void ms_eqs_sim(%s, int has_next, double* out) {' % C2)
     w('  int i = 0; (void)i; (void)has_next; (void)out; (void)next;')

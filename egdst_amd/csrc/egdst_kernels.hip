@@ -2271,6 +2271,12 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
     cp.cash = m0;
     cp.savings = 0;
     cp.shock = NAN;
+#if MS_NCONT > 0
+    // continuous states (egdst_simulator.c:91-92,237-246): the model functions read states and decisions BY VALUE
+    cp.byval = np_.byval = 1;
+    for (int k = 0; k < MS_NNST; k++) cp.st[k] = ms_states[ist0 + k * MS_NST], np_.st[k] = 0;
+    for (int k = 0; k < MS_NND; k++) cp.dc[k] = np_.dc[k] = 0;
+#endif
     for (int it = 0; it < nt; it++) {
         if (it == 0) {
             if (!ms_feasible(&E, &cp)) return;
@@ -2287,14 +2293,25 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
             if (r2 > ms_survival(&E, &cp)) return;  // death: remaining periods stay NaN
             double pr = 0;
             for (np_.ist = 0; np_.ist < MS_NST; np_.ist++) {
+#if MS_NCONT > 0
+                {   // only the first grid point of every continuous state; their values travel in st[] (:274-280)
+                    int k = 0;
+                    for (; k < MS_NNST; k++)
+                        if (ms_stcont[k] && (np_.ist / ms_ststride[k]) % ms_stsize[k] != 0) break;
+                    if (k < MS_NNST) continue;
+                    for (k = 0; k < MS_NNST; k++)
+                        if (!ms_stcont[k]) np_.st[k] = ms_states[np_.ist + k * MS_NST];
+                    ms_trpr_cont(&E, &cp, &np_);
+                }
+#endif
                 if (!ms_feasible(&E, &np_)) continue;
                 if (MS_OPTIM_TRPRNOSH)
-                    pr = ms_trpr(&E, &cp, &np_, &terr);
+                    pr = ms_trpr_discrete(&E, &cp, &np_, &terr);
                 else {
                     mu = ms_mu(&E, &cp, &np_);
                     sigma = ms_sigma(&E, &cp, &np_);
                     np_.shock = (sigma <= 0) ? eg_shock_mean(&E, &cp, &np_) : eg_shock_uniform(r1, mu, sigma);
-                    pr = ms_trpr(&E, &cp, &np_, &terr);
+                    pr = ms_trpr_discrete(&E, &cp, &np_, &terr);
                 }
                 r0 -= pr;
                 if (r0 <= 0) break;
@@ -2312,6 +2329,63 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
             ms_eqs_sim(&E, &cp, &np_, 1, eqs);
             cp = np_;
         }
+#if MS_NCONT > 0
+        // Consumption interpolated over the 2^k grid corners around the continuous states; the (state, decision) pair is
+        // drawn among the corners by their weights with the fixed number .5 (egdst_simulator.c:318-372).  The reference
+        // calls policy() without the value function there and adds up its uninitialised period buffer: the value
+        // function column is 0 here (what a zeroed buffer gives).
+        double c = 0, vf = 0.0;
+        {
+            const int nw = 1 << MS_NCONT, ist_base = cp.ist;
+            double wts[1 << MS_NCONT], wc = 0, rr = .5;
+            int wist[1 << MS_NCONT], ist1 = -1, id1 = 0;
+            for (int ii = 0; ii < nw; ii++) wts[ii] = 1, wist[ii] = ist_base;
+            for (int q = 0, k = 0; k < MS_NNST; k++) {
+                if (!ms_stcont[k]) continue;
+                const double *g = ms_stgrid(k);
+                const int j1 = ms_bxsearch(cp.st[k], g, ms_stsize[k]);
+                for (int ii = 0; ii < nw; ii++) {
+                    if ((ii >> q) % 2 == 0) {
+                        wts[ii] *= (g[j1 + 1] - cp.st[k]) / (g[j1 + 1] - g[j1]);
+                        wist[ii] += ms_ststride[k] * j1;
+                    } else {
+                        wts[ii] *= (cp.st[k] - g[j1]) / (g[j1 + 1] - g[j1]);
+                        wist[ii] += ms_ststride[k] * (j1 + 1);
+                    }
+                }
+                q++;
+            }
+            for (int ii = 0; ii < nw; ii++) {
+                if (!(wts[ii] > 0)) continue;
+                const int is_ = wist[ii];
+                if (is_ < 0 || is_ >= MS_NST) {
+                    atomicCAS(a.err, 0, EGDST_E_NOT_SOLVED);
+                    return;
+                }
+                const Tab t = eg_tab(b, it, draw, is_);
+                if (t.len < 2) {
+                    atomicCAS(a.err, 0, EGDST_E_NOT_SOLVED);
+                    return;
+                }
+                const int i = eg_bracket(cp.cash, t.M, t.len, 0);
+                const double cc = eg_lerp(cp.cash, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
+                int ith = 0;
+                while (ith < t.thlen && cp.cash >= t.TH[ith]) ith++;
+                wc += cc * wts[ii];
+                rr -= wts[ii];
+                if (rr < 0 && ist1 == -1) ist1 = is_, id1 = (int)t.D[max(ith - 1, 0)];
+            }
+            if (ist1 < 0) {
+                atomicCAS(a.err, 0, EGDST_E_NOT_SOLVED);
+                return;
+            }
+            c = MS_MIN(wc, cp.cash - b.g.a0);
+            cp.savings = cp.cash - c;
+            cp.ist = ist1;
+            cp.id = id1;
+            for (int k = 0; k < MS_NND; k++) cp.dc[k] = ms_decisions[cp.id + k * MS_ND];
+        }
+#else
         // policy at (it, ist)
         const Tab t = eg_tab(b, it, draw, cp.ist);
         if (t.len < 2) {
@@ -2329,6 +2403,7 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
             vf = ms_utility(&E, &cp, c) + ms_discount(&E, &cp) * t.V[0];
         else
             vf = eg_lerp(cp.cash, t.M[i], t.M[i + 1], t.V[i], t.V[i + 1]);
+#endif
         double *o = a.sims + ((size_t)isim * nt + it) * a.nout;
         o[0] = cp.cash;
         o[1] = c;
@@ -2341,7 +2416,11 @@ __global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
         o[8] = cp.shock;
         o[9] = ms_utility(&E, &cp, c);
         o[10] = ms_discount(&E, &cp);
+#if MS_NCONT > 0
+        for (int k = 0; k < MS_NNST; k++) o[11 + k] = cp.st[k];  // exact values of the continuous states (:138)
+#else
         for (int k = 0; k < MS_NNST; k++) o[11 + k] = ms_states[cp.ist + k * MS_NST];
+#endif
         for (int k = 0; k < MS_NND; k++) o[11 + MS_NNST + k] = ms_decisions[cp.id + k * MS_ND];
         for (int k = 0; k < MS_NEQ; k++) o[11 + MS_NNST + MS_NND + k] = eqs[k];
     }

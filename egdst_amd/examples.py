@@ -285,6 +285,43 @@ def retirement_mortal(**over):
     return _apply(m, over)
 
 
+def retirement_hc(**over):
+    """model_retirement2.m forms plus a CONTINUOUS state -- human capital on a 5-point grid over [0, 2]
+    that grows while working and depreciates otherwise (deterministic motion rules, egdstmodel.m:166-169) and scales the
+    wage.  No shipped script has a continuous state; this one exercises trpr(..., all=1) in the solver
+    (compile.m:527-538) and the 2^k corner blend of the simulator (egdst_simulator.c:313-372)."""
+    m = egdstmodel('retirehc')
+    m.t0 = 1
+    m.T = 20
+    m.mmax = 10
+    m.ngridmax = 1000
+    m.ngridm = 80
+    m.nthrhmax = 100
+    m.ny = 5
+    m.s = ('Human capital', [0.0, 2.0], 5)
+    m.trpr = ('dc1==1', 'min(st1*0.9+0.3,2.0)')
+    m.trpr = ('dc1==0', 'st1*0.9')
+    m.feasible = ('defaultfeasible', True)
+    m.d = ('Labour supply', [0, 'retire', 1, 'work'])
+    m.choiceset = ('defaultallow', True)
+    m.u = ('utility', 'log(consumption)+duw*(id==0)')
+    m.param = ('duw', 'disutility of work', 0.5)
+    m.u = ('marginal', '1/consumption')
+    m.u = ('marginalinverse', '1/mutility')
+    m.u = ('extrap', 'log(x)')
+    m.budget = ('cashinhand', 'savings*(1+interest)+wage_income*(id!=0)')
+    m.budget = ('marginal', '1+interest')
+    m.discount = '1/(1+interest)'
+    m.param = ('interest', 'return on savings', 0.045)
+    m.eq = ('wage_income', 'Realized wage income', 'wage*(0.6+0.4*st1n)*shock', 'next')
+    m.param = ('wage', 'wage (times multiplicator shock)', 1.05)
+    m.a0 = 0
+    m.shock = 'lognormal'
+    m.shock = ('sigma', '0.25')
+    m.shock = ('mu', '-0.5*sigma*sigma')
+    return _apply(m, over)
+
+
 REGISTRY = {'deaton1': deaton1, 'deaton2': deaton2, 'deaton_sig': deaton_sig, 'retirement1': retirement1,
             'retirement2': retirement2, 'retirement_sig': retirement_sig, 'occ3': occ3, 'model2': model2,
-            'retirement8': retirement8, 'cake_normal': cake_normal, 'retirement_mortal': retirement_mortal}
+            'retirement8': retirement8, 'cake_normal': cake_normal, 'retirement_mortal': retirement_mortal, 'retirement_hc': retirement_hc}

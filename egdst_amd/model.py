@@ -235,9 +235,18 @@ class egdstmodel:  # noqa: N801  (reference class name)
         elif (isinstance(value, (tuple, list)) and len(value) == 2 and isinstance(value[0], str)):
             vals = [float(x) for x in np.atleast_1d(value[1])]
             lst.append(_Var(len(lst) + 1, value[0], 'discrete', vals, ['value %1.3f' % x for x in vals]))
-        elif (isinstance(value, (tuple, list)) and len(value) == 3 and isinstance(value[0], str)):
-            # continuous variables ({'label',[x0 x1],N}) are SURVEY §8(f) N4: not in this round
-            raise EgdstError('Continuous %s variables are not implemented in this build (SURVEY §8f N4)' % what)
+        elif (isinstance(value, (tuple, list)) and len(value) == 3 and isinstance(value[0], str)
+              and len(np.atleast_1d(value[1])) == 2 and np.isscalar(value[2])):
+            # name + grid limits + number of grid points: a CONTINUOUS variable on a linspace grid whose points double
+            # as its "values" (egdstmodel.m:628-646); decisions of this type are not part of the hot path
+            if what != 'state':
+                raise EgdstError('Continuous decision variables are not implemented')
+            lim = [float(x) for x in np.atleast_1d(value[1])]
+            n = int(value[2])
+            if n < 2:
+                raise EgdstError('A continuous state variable needs at least two grid points')
+            grid = [float(x) for x in np.linspace(lim[0], lim[1], n)]
+            lst.append(_Var(len(lst) + 1, value[0], 'continuous', grid, ['grid point'] * n, lim, n))
         else:
             raise EgdstError('Unrecognized structure for %s variable!' % what)
 
@@ -454,7 +463,13 @@ class egdstmodel:  # noqa: N801  (reference class name)
         vi, cond, mat = value
         n = self.stm[vi - 1]
         if isinstance(mat, str):
-            raise EgdstError('Motion rules of continuous states are not implemented in this build (SURVEY §8f N4)')
+            # varindex + condition + executable string: the deterministic motion rule of a continuous state
+            # (egdstmodel.m:997-1003)
+            while len(self._trpr) < vi:
+                self._trpr.append(_Trpr(0))
+            self._trpr[vi - 1].varindex = vi
+            self._trpr[vi - 1].cases.append(_Case(cond, mat))
+            return
         rows = [list(r) for r in mat]
         if len(rows) != n or any(len(r) != n for r in rows):
             raise EgdstError('Unrecognized structure for trpr definition!')

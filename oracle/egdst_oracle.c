@@ -420,10 +420,10 @@ static double seg_val(const env_t *e, int f, int k, double x, int which)
 static double analytic_val(const env_t *e, int f, double x)
 {
     ms_pv cv;
+    memset(&cv, 0, sizeof cv); /* (byval = 0: the solver reads states and decisions from the tables) */
     cv.it = e->it;
     cv.ist = e->ist;
     cv.id = f;
-    cv.cash = cv.savings = cv.shock = 0;
     return ms_utility(&e->c->E, &cv, x - e->c->E.a0) + ms_discount(&e->c->E, &cv) * e->evfa0[f];
 }
 
@@ -977,7 +977,7 @@ int egdst_oracle_solve(const orc_desc *d, const double *par, orc_solution *sol)
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* simulator (egdst_simulator.c:47-383; models whose states are all discrete) */
+/* simulator (egdst_simulator.c:47-383), models with continuous states included (:313-372) */
 
 typedef struct {
     ms_pv pv;
@@ -1036,6 +1036,10 @@ int egdst_oracle_sim(const orc_desc *d, const double *par, const orc_solution *s
                 cp->pv.it = 0;
                 cp->pv.ist = ist0;
                 cp->pv.cash = m0;
+#if MS_NCONT > 0
+                sp[0].pv.byval = sp[1].pv.byval = 1; /* :91-92: model functions read st[] and dc[] by value */
+                for (i = 0; i < MS_NNST; i++) cp->pv.st[i] = ms_states[ist0 + i * MS_NST];
+#endif
                 if (!ms_feasible(&E, &cp->pv)) break;
                 cp->mu = cp->sigma = cp->pv.shock = NAN;
                 ms_eqs_sim(&E, &cp->pv, &cp->pv, 0, cp->eqs);
@@ -1049,9 +1053,19 @@ int egdst_oracle_sim(const orc_desc *d, const double *par, const orc_solution *s
                 r2 = rs[irnd++];
                 if (r2 > ms_survival(&E, &cp->pv)) break;
                 for (np_->pv.ist = 0; np_->pv.ist < MS_NST; np_->pv.ist++) {
+#if MS_NCONT > 0
+                    /* only the first grid point of every continuous state is looked at: the state index keeps the
+                       discrete variables, the continuous ones are carried by value (:274-280) */
+                    for (i = 0; i < MS_NNST; i++)
+                        if (ms_stcont[i] && (np_->pv.ist / ms_ststride[i]) % ms_stsize[i] != 0) break;
+                    if (i < MS_NNST) continue;
+                    for (i = 0; i < MS_NNST; i++)
+                        if (!ms_stcont[i]) np_->pv.st[i] = ms_states[np_->pv.ist + i * MS_NST];
+                    ms_trpr_cont(&E, &cp->pv, &np_->pv);
+#endif
                     if (!ms_feasible(&E, &np_->pv)) continue;
                     if (MS_OPTIM_TRPRNOSH)
-                        pr = ms_trpr(&E, &cp->pv, &np_->pv, &terr);
+                        pr = ms_trpr_discrete(&E, &cp->pv, &np_->pv, &terr);
                     else {
                         np_->mu = ms_mu(&E, &cp->pv, &np_->pv);
                         np_->sigma = ms_sigma(&E, &cp->pv, &np_->pv);
@@ -1059,7 +1073,7 @@ int egdst_oracle_sim(const orc_desc *d, const double *par, const orc_solution *s
                             np_->pv.shock = shock_expectation(&E, &cp->pv, &np_->pv);
                         else
                             np_->pv.shock = shock_from_uniform(r1, np_->mu, np_->sigma);
-                        pr = ms_trpr(&E, &cp->pv, &np_->pv, &terr);
+                        pr = ms_trpr_discrete(&E, &cp->pv, &np_->pv, &terr);
                     }
                     r0 -= pr;
                     if (r0 <= 0) break;
@@ -1077,8 +1091,53 @@ int egdst_oracle_sim(const orc_desc *d, const double *par, const orc_solution *s
                 ms_eqs_sim(&E, &cp->pv, &np_->pv, 1, np_->eqs);
                 cp = np_;
             }
+#if MS_NCONT > 0
+            {   /* consumption interpolated over the 2^k grid corners around the continuous states, the (state, decision)
+                   pair drawn among the corners by their weights with the fixed "random" number .5 (:318-372).  policy()
+                   is called with dovf = 0 there, so the value function column is never computed: the reference adds up
+                   whatever its uninitialised period buffer holds; a zeroed buffer gives 0, which is what is written here */
+                int nw = 1 << MS_NCONT, ii, q, ist_base = cp->pv.ist, ist1 = -1, id1 = 0;
+                double wts[1 << MS_NCONT], wc = 0, rr = .5;
+                int wist[1 << MS_NCONT];
+                for (ii = 0; ii < nw; ii++) wts[ii] = 1, wist[ii] = ist_base;
+                for (q = 0, i = 0; i < MS_NNST; i++) {
+                    const double *g;
+                    int j1;
+                    if (!ms_stcont[i]) continue;
+                    g = ms_stgrid(i);
+                    j1 = ms_bxsearch(cp->pv.st[i], g, ms_stsize[i]);
+                    for (ii = 0; ii < nw; ii++) {
+                        if ((ii >> q) % 2 == 0) {
+                            wts[ii] *= (g[j1 + 1] - cp->pv.st[i]) / (g[j1 + 1] - g[j1]);
+                            wist[ii] += ms_ststride[i] * j1;
+                        } else {
+                            wts[ii] *= (cp->pv.st[i] - g[j1]) / (g[j1 + 1] - g[j1]);
+                            wist[ii] += ms_ststride[i] * (j1 + 1);
+                        }
+                    }
+                    q++;
+                }
+                for (ii = 0; ii < nw; ii++) {
+                    if (!(wts[ii] > 0)) continue;
+                    cp->pv.ist = wist[ii];
+                    if (cp->pv.ist < 0 || cp->pv.ist >= MS_NST || sol->len[(size_t)it * MS_NST + cp->pv.ist] < 2) return -4;
+                    sim_policy(&E, d, sol, cp);
+                    wc += cp->c * wts[ii];
+                    rr -= wts[ii];
+                    if (rr < 0 && ist1 == -1) ist1 = wist[ii], id1 = cp->pv.id;
+                }
+                cp->c = MS_MIN(wc, cp->pv.cash - d->a0);
+                cp->pv.savings = cp->pv.cash - cp->c;
+                cp->vf = 0.0;
+                cp->pv.ist = ist1;
+                cp->pv.id = id1;
+                if (ist1 < 0) return -4;
+                for (i = 0; i < MS_NND; i++) cp->pv.dc[i] = ms_decisions[cp->pv.id + i * MS_ND];
+            }
+#else
             if (cp->pv.ist >= MS_NST || sol->len[(size_t)it * MS_NST + cp->pv.ist] < 2) return -4; /* "Solution not found" */
             sim_policy(&E, d, sol, cp);
+#endif
             {
                 double *o = sims + ((size_t)isim * nt + it) * nout;
                 o[0] = cp->pv.cash;
@@ -1092,7 +1151,11 @@ int egdst_oracle_sim(const orc_desc *d, const double *par, const orc_solution *s
                 o[8] = cp->pv.shock;
                 o[9] = ms_utility(&E, &cp->pv, cp->c);
                 o[10] = ms_discount(&E, &cp->pv);
+#if MS_NCONT > 0
+                for (i = 0; i < MS_NNST; i++) o[11 + i] = cp->pv.st[i];   /* exact values of the continuous states (:138) */
+#else
                 for (i = 0; i < MS_NNST; i++) o[11 + i] = ms_states[cp->pv.ist + i * MS_NST];
+#endif
                 for (i = 0; i < MS_NND; i++) o[11 + MS_NNST + i] = ms_decisions[cp->pv.id + i * MS_ND];
                 for (i = 0; i < MS_NEQ; i++) o[11 + MS_NNST + MS_NND + i] = cp->eqs[i];
             }

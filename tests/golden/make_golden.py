@@ -29,6 +29,9 @@ CASES = {
     'occ3': lambda: examples.occ3(),
     'model2': lambda: examples.model2(T=12, ngridm=60, nquad=5, sigma=0.2, r=0.02, df=0.95),
     'retire8': lambda: examples.retirement8(T=6, ngridm=40, ny=3),
+    'cakenormal': lambda: examples.cake_normal(),          # additive normal shocks (DISTRIB=2)
+    'retiremortal': lambda: examples.retirement_mortal(),  # survival < 1: deaths in the simulated panel
+    'retirehc': lambda: examples.retirement_hc(),          # a continuous state
 }
 
 
@@ -58,7 +61,10 @@ def pack(model, native):
     # simulation: 6 agents spread over states and cash, own shocks
     rng = np.random.default_rng(12345)
     nsim = 6
-    init = np.stack([1 + (np.arange(nsim) % nst), np.linspace(max(d['a0'], 0) + 0.25, 0.8 * d['mmax'], nsim)], axis=1)
+    # (with continuous states the reference double-counts the grid index of the initial state, egdst_simulator.c:319:
+    # initial states beyond the middle of the grid run off the cell array; the fixtures start below it)
+    nst0 = 3 if any(v.type == 'continuous' for v in model.s) else nst
+    init = np.stack([1 + (np.arange(nsim) % nst0), np.linspace(max(d['a0'], 0) + 0.25, 0.8 * d['mmax'], nsim)], axis=1)
     rs = rng.random(4 * nt * nsim)
     out['sim_init'], out['sim_rand'] = init, rs
     out['sims'] = orc.sim(sol, init, rs, rndtype=0)
@@ -67,6 +73,8 @@ def pack(model, native):
 
 if __name__ == '__main__':
     for name, mk in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         for native in (True, False):
             f = os.path.join(HERE, '%s_%s.npz' % (name, 'native' if native else 'portable'))
             np.savez_compressed(f, **pack(mk(), native))

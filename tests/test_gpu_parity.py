@@ -454,3 +454,33 @@ def test_class_surface_dbgout():
     m.compile()
     m.solve(dbgout=True)
     assert m.dbgout.shape == (m.nt * 1 * 2 * 2 * m.nt, 7) and m.dbgout[0, 0] == m.nt - 2 and m.dbgout[0, 2] == -1
+
+
+def test_continuous_state_model_solver_simulator_accessor():
+    """a continuous state on a grid with deterministic motion rules.  Solver: the transition weights of
+    trpr(..., all=1) (compile.m:527-538).  Simulator: exact state values, consumption blended over the 2^k grid corners,
+    the (state, decision) pair drawn by the weights (egdst_simulator.c:313-372), including the gateway's failure for
+    initial states beyond the middle of the grid.  Bit for bit against the oracle."""
+    m = examples.retirement_hc()
+    s = gpu_solve(m)
+    orc = Oracle(m)
+    ref = orc.solve()
+    sol = s.solution(0)
+    assert ref.rc == 0 and sol.status == 0
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    assert sol.nevals == ref.nevals
+    rng = np.random.default_rng(3)
+    nsim = 500
+    init = np.column_stack([rng.integers(1, 4, nsim), rng.uniform(0.2, 9, nsim)])
+    rs = rng.random(4 * m.nt * nsim)
+    for rndtype in (0, 1):
+        a, b_ = s.simulate(init, rs, rndtype=rndtype), orc.sim(ref, init, rs, rndtype=rndtype)
+        assert np.array_equal(a, b_, equal_nan=True)
+    hc = a[:, :, 11]
+    assert hc.min() >= 0 and hc.max() <= 2 and len(np.unique(hc)) > 10       # the state really is continuous (off-grid values)
+    with pytest.raises(runtime.EgdstRuntimeError):
+        s.simulate(np.array([[5, 2.0]]), rs)
+    from call_cases import call_cases
+    for sw, args in call_cases(m, s.nt, s.lib.info.nst, s.lib.info.nd):
+        assert np.array_equal(s.call(sw, args), orc.call(ref, sw, args), equal_nan=True), sw

@@ -110,3 +110,19 @@ def test_call_needs_a_solved_model_and_known_names():
     assert egdstmodel.CALL_NAMES['u'] == egdstmodel.CALL_NAMES['utility'] == 1
     assert egdstmodel.CALL_NAMES['mu'] == 2 and egdstmodel.CALL_NAMES['df'] == 3
     assert egdstmodel.CALL_NAMES['b'] == 4 and egdstmodel.CALL_NAMES['mb'] == 5 and egdstmodel.CALL_NAMES['vf'] == 6
+
+
+def test_continuous_state_dsl_and_generated_plugin():
+    """egdstmodel.m:628-646,997-1003 / compile.m:26-34,527-575: a continuous state is a linspace grid whose points are its
+    values; its trpr entries are motion-rule strings; the plugin reads states by value when the simulator asks for it."""
+    from egdst_amd import codegen, examples
+    m = examples.retirement_hc()
+    assert m.nst == 5 and m.nnst == 1 and m.s[0].type == 'continuous' and m.s[0].gridpoints == 5
+    assert np.allclose(m.states[:, 0], np.linspace(0, 2, 5)) and m.stm == [5, 1]
+    assert isinstance(m.trpr[0].cases[0].prob, str) and len(m.trpr[0].cases) == 2
+    text = codegen.generate_modelspec(m)
+    assert '#define MS_NCONT 1' in text and 'ms_trpr_cont' in text and 'ms_bxsearch(nval, ms_stgrid1, 5)' in text
+    assert 'curr->byval>0?curr->st[0]:ms_states[curr->ist+0*MS_NST]' in text
+    assert '#define MS_NCONT 0' in codegen.generate_modelspec(examples.retirement2())
+    with pytest.raises(Exception):
+        m.d = ('a continuous decision', [0, 1], 4)
