@@ -70,6 +70,8 @@ struct Batch {
     int *dbg;             // [16*ndraw] diagnostics of a tripped internal guard
     double *klog;         // kink log (the gateway's dbgout): [(it*ndraw+draw)*MS_NST+ist][kcap][4], or nullptr (egdst_set_dbgout)
     int *kcnt, kcap;      // kinks recorded per cell; capacity of a cell's slice
+    unsigned *segstat;    // [2*ndraw] walks of the draw that were cut into segments and merged / that fell back to one wave
+    int noseg;            // 1: envelope walks are never cut into segments (environment EGDST_NOSEG at create; diagnostics)
     double *obj;          // [2*ndraw] staging of k_objective for the host-returning entry point
     unsigned long long *algbytes;  // [ndraw] compulsory table traffic: 24 B per next-period row read once per
                                    // period + 24 B per row written + 16 B per threshold

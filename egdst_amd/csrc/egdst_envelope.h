@@ -56,6 +56,7 @@ template <bool L> struct EnvCtxT {
     double *klog;   // kink log of this cell (the gateway's dbgout, egdst_solver.c:1866-1879): 4 doubles per recorded kink
     int *kcnt;      // -- (choice whose secondary envelope runs or -1, threshold, consumption left, right); nullptr: off
     int kcap;
+    int later;      // 1: this context walks a LATER SEGMENT of the stream (run_walk): rows and thresholds exist before it
     int err;
 };
 
@@ -345,13 +346,13 @@ template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e,
         e.err = 2708;
         return false;
     }
-    if (e.oi > 0 && e.lastg == x) {  // duplicate grid point (:1290-1298)
+    if ((e.oi > 0 || e.later) && e.lastg == x) {  // duplicate grid point (:1290-1298)
         e.cur[f]++;
         return true;
     }
     const int self = env_at(e, f, e.cur[f] + 1);
     double fv = e.v[self];
-    if (e.oj == 0) {  // first point of the common grid (:1303-1347)
+    if (e.oj == 0 && !e.later) {  // first point of the common grid (:1303-1347)
         double t = fv;
         e.ci = f;
         for (int j = 0; j < e.nf; j++) {
@@ -655,14 +656,14 @@ template <bool L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L
         return false;
     }
     const int curf = e.cur[f];
-    if (e.oi > 0 && e.lastg == x) {  // duplicate grid point (:1290-1298)
+    if ((e.oi > 0 || e.later) && e.lastg == x) {  // duplicate grid point (:1290-1298)
         EG_WSYNC();
         if (lane == 0) e.cur[f] = curf + 1;
         return true;
     }
     const int self = env_at(e, f, curf + 1);
     double fv = e.v[self];
-    if (e.oj == 0) {  // first point of the common grid (:1303-1347)
+    if (e.oj == 0 && !e.later) {  // first point of the common grid (:1303-1347)
         // the highest function at x, own value included, smallest index among equals
         double t = fv;
         int cj = (lane == (f & (EG_WAVE - 1))) ? f : -1;
@@ -874,10 +875,16 @@ static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typ
     }
 }
 
-// lane 0 takes one generic step; the few scalars the other lanes need are broadcast afterwards
-template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts)
+// Walks the sorted positions [p0, p1).  later == 0: from the start of the stream (p0 == 0) with the reference's initial
+// state.  later == 1: a later segment (run_walk): starts in the regular phase with the current max function pm0 and the
+// last output grid value lastg0 that the preceding segment is PREDICTED to end with; rows and thresholds are counted
+// from 0 in this segment's own output region.  On return e.pm / e.lastg hold the state after position p1-1.
+template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, int p0 = 0, int p1 = -1, int later = 0,
+                                                                       int pm0 = -1, double lastg0 = 0)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
+    if (p1 < 0) p1 = npts;
+    e.later = later;
 #ifdef EGDST_SEQ_WALK  // diagnostic build: the plain sequential walk on lane 0
     if (lane == 0) env_walk(e, npts);
     __threadfence_block();
@@ -896,29 +903,29 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
         e.bound = bound;
         e.oi = e.oj = 0;
         e.ci = 0;
-        e.lastg = -INFINITY;
-        e.pm = -1;
+        e.lastg = later ? lastg0 : -INFINITY;
+        e.pm = later ? pm0 : -1;
         if (lane == 0)
             for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
         e.err = __shfl(e.err, 0);
     }
     // phase 0: the first point(s) until a current-max function exists; phase 1: batches of EG_WAVE positions;
     // phase 2: the grid values at the bound (last point of the shortest function).  One generic-step site.
-    int i = 0, pm = -1, phase = 0;
-    double lastg = -INFINITY;
+    int i = p0, pm = e.pm, phase = later ? 1 : 0;
+    double lastg = e.lastg;
 #ifdef EGDST_STAMPS
     unsigned long long w_t0 = wall_clock64(), w_step = 0, w_batch = 0, w_nstep = 0, w_nbatch = 0;
 #define WSTAMP(acc, cnt) do { unsigned long long n_ = wall_clock64(); acc += n_ - w_t0; w_t0 = n_; cnt++; } while (0)
 #else
 #define WSTAMP(acc, cnt)
 #endif
-    while (i < npts && !e.err) {
+    while (i < p1 && !e.err) {
         bool step_now = true;
         if (phase != 1) {
             if (!(e.m[i] <= e.bound)) break;
         } else {
             const int p = i + lane;
-            const bool valid = p < npts && e.m[p] < e.bound;
+            const bool valid = p < p1 && e.m[p] < e.bound;
             const unsigned long long vmask = __ballot(valid);
             if (!(vmask & 1ull)) {  // position i is at (or beyond) the bound: sequential tail with rebuilt cursors
                 for (int j = lane; j < e.nf; j += EG_WAVE) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
@@ -995,6 +1002,8 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
             WSTAMP(w_step, w_nstep);
         }
     }
+    e.pm = pm;
+    e.lastg = lastg;
 #ifdef EGDST_STAMPS
     if (lane == 0 && e.dbg) {
         atomicAdd((unsigned long long *)e.dbg + 3, (w_nbatch << 32) | w_nstep);

@@ -1460,6 +1460,12 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
         }                                                \
         return;                                          \
     } while (0)
+#define ENV_MAXSEG 8            // segments of a walk (one wave each)
+#define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per segment
+#define ENV_SEGNF 126           // functions a segmented walk can handle (2*(nf+2) stack entries per slice)
+#ifndef ENV_SEG_MINPTS
+#define ENV_SEG_MINPTS 192      // sorted points per segment below which cutting a walk is not worth it
+#endif
 #define ENV_SMALLF 1024  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
                          // (C5 at full size: 292 pieces in one list; the reference allows 10000, :832)
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
@@ -1471,6 +1477,10 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
     const eg_ldsd *evfa0;
     eg_ldsi *stack;
     int *dbg;
+    int noseg;     // 1: never cut the walk into segments (EGDST_NOSEG; tests compare both ways)
+    unsigned *segstat;  // [2] of the draw: segmented walks merged / fallen back
+    double *wM, *wV, *wC;  // scratch rows for the segments of a cut walk ([wcap] each; work arrays that are free while walking)
+    int wcap;
     double *klog;  // kink log of the cell (dbgout), or nullptr
     int *kcnt;
     int kcap;
@@ -1520,6 +1530,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     e.kcnt = j.kcnt;
     e.kcap = j.kcap;
     e.err = 0;
+    e.later = 0;
     e.bound = 0;
     e.ci = 0;
     e.oi = e.oj = 0;
@@ -1555,6 +1566,132 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifdef EGDST_STAMPS
     if (threadIdx.x == 0 && j.dbg) atomicAdd((unsigned long long *)j.dbg + 1, wall_clock64() - pc0_);
 #endif
+    // ---- segmented walk ----------------------------------------------------------------------------------------
+    // The walk is a state machine over the sorted positions, but its state after a position is small -- the current max
+    // function and the grid value of the last output row (the cursors are rebuilt from counts at every event) -- and
+    // PREDICTABLE at most positions: after a point that no other function lies above (class bit 0 clear) the walk has
+    // kept that point, so the current max is the point's function and the last grid value is its M.  The stream is
+    // therefore cut at such points into as many segments as the workgroup has waves, every wave walks one segment from
+    // its predicted start state into a region of its own in the output arrays, and afterwards the predictions are
+    // CHECKED against the true end states of the preceding segments: if every one holds (and nothing overflowed), the
+    // concatenation of the segments' outputs is exactly what the sequential walk writes (by induction from segment 0,
+    // which starts from the true initial state) and is compacted in place; otherwise -- an exact tie at a cut, an error,
+    // a full grid -- wave 0 simply does the whole walk again sequentially.  Same code per position either way.
+    __shared__ int sg_p[ENV_MAXSEG + 1], sg_oi[ENV_MAXSEG], sg_oj[ENV_MAXSEG], sg_err[ENV_MAXSEG], sg_pm[ENV_MAXSEG], sg_n;
+    __shared__ double sg_lastg[ENV_MAXSEG];
+    const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
+    int nseg = 1, thstride = j.nthrhmax;
+#if !defined(EGDST_SEQ_WALK)
+    {
+        nseg = ENV_BS / WAVE;
+        if (nseg > ENV_MAXSEG) nseg = ENV_MAXSEG;
+        while (nseg > 1 && j.npts < ENV_SEG_MINPTS * nseg) nseg--;  // (a segment should be worth a few batches)
+        // every segment writes its rows and thresholds into a region of its own in scratch arrays (rows: up to twice its
+        // points plus 64; thresholds: the last 2*nthrhmax entries, thstride per segment)
+        if (j.klog || !j.wM || j.nf > ENV_SEGNF || nseg < 2 ||
+            2 * (long long)j.npts + 64 * nseg + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap)
+            nseg = 1;
+        thstride = j.nthrhmax / nseg;
+        if (thstride < 8) nseg = 1, thstride = j.nthrhmax;
+        if (j.noseg) nseg = 1, thstride = j.nthrhmax;
+    }
+#endif
+    if (nseg > 1) {
+        // cuts: the first position at or after s*npts/nseg whose point nothing lies above (and which is below the bound:
+        // such class words are never negative); one lane per cut, then thread 0 keeps the increasing ones
+        if (tid_ >= 1 && tid_ < nseg) {
+            int q = (int)((long long)tid_ * j.npts / nseg);
+            const int lim = min(j.npts - 2, q + 6 * WAVE);
+            while (q < lim && (cls[q] < 0 || (cls[q] & 1))) q++;
+            sg_p[tid_] = (q < lim) ? q + 1 : -1;
+        }
+        __syncthreads();
+        if (tid_ == 0) {
+            int n = 1, prev = 0;
+            sg_p[0] = 0;
+            for (int k = 1; k < nseg; k++) {
+                const int pk = sg_p[k];
+                if (pk > prev + WAVE) sg_p[n++] = pk, prev = pk;
+            }
+            sg_p[n] = j.npts;
+            sg_n = n;
+        }
+        __syncthreads();
+        nseg = sg_n;
+    }
+    if (nseg > 1) {
+        double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
+        if (wave_ < nseg) {
+            EnvCtxT<L> es = e;
+            const int sgi = wave_, p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
+            const size_t row0 = 2 * (size_t)p0 + 64 * (size_t)sgi;
+            es.cur = j.cur + sgi * ENV_SEGNF_SLICE;
+            es.mark = j.mark + sgi * ENV_SEGNF_SLICE;
+            es.stack = j.stack + sgi * 2 * ENV_SEGNF_SLICE;
+            es.stackcap = 2 * ENV_SEGNF_SLICE;
+            es.og = j.wM + row0, es.ov = j.wV + row0, es.oc = j.wC + row0;
+            es.ocap = 2 * (p1 - p0) + 64;
+            es.oth = wTH + (size_t)sgi * thstride, es.oix = wIX + (size_t)sgi * thstride;
+            es.nthrhmax = thstride;
+            int pm0 = -1;
+            double lastg0 = 0;
+            if (sgi > 0) pm0 = (int)f[p0 - 1], lastg0 = m[p0 - 1];
+#ifdef EGDST_STAMPS
+            const unsigned long long sgt0_ = wall_clock64();
+#endif
+            env_walk_wave(es, j.npts, p0, p1, sgi > 0 ? 1 : 0, pm0, lastg0);
+#ifdef EGDST_STAMPS
+            if (lane_ == 0 && j.dbg) {  // diagnostic: longest segment (slot 0) and sum over segments (slot 1, was: classification)
+                const unsigned long long d_ = wall_clock64() - sgt0_;
+                atomicMax((unsigned long long *)j.dbg + 0, d_);
+                atomicAdd((unsigned long long *)j.dbg + 1, d_);
+            }
+#endif
+            if (lane_ == 0) {
+                sg_oi[sgi] = es.oi, sg_oj[sgi] = es.oj, sg_err[sgi] = es.err, sg_pm[sgi] = es.pm;
+                sg_lastg[sgi] = es.lastg;
+            }
+        }
+        __syncthreads();
+        if (tid_ == 0) {  // do the predictions hold?
+            int ok = 1, toi = 0, toj = 0;
+            for (int k = 0; k < nseg; k++) {
+                if (sg_err[k]) ok = 0;
+                toi += sg_oi[k], toj += sg_oj[k];
+                if (k + 1 < nseg) {
+                    const int q = sg_p[k + 1] - 1;
+                    if (sg_pm[k] != (int)f[q] || !(sg_lastg[k] == m[q])) ok = 0;
+                }
+            }
+            if (sg_oj[0] <= 0) ok = 0;                             // (segment 0 must have left the first-point phase)
+            if (toi >= j.ocap || toj >= j.nthrhmax) ok = 0;      // a full grid or threshold list: the sequential walk reports it
+            sg_n = ok ? nseg : 0;
+            atomicAdd(&j.segstat[ok ? 0 : 1], 1u);
+        }
+        __syncthreads();
+        if (sg_n) {
+            // gather: the segments' rows and thresholds, in order, to the front of the output
+            int off = 0, offj = 0;
+            for (int k = 0; k < nseg; k++) {
+                const size_t src = 2 * (size_t)sg_p[k] + 64 * (size_t)k;
+                const int cnt = sg_oi[k], cntj = sg_oj[k];
+                for (int r = tid_; r < cnt; r += ENV_BS) {
+                    j.og[off + r] = j.wM[src + r];
+                    j.ov[off + r] = j.wV[src + r];
+                    j.oc[off + r] = j.wC[src + r];
+                }
+                for (int r = tid_; r < cntj; r += ENV_BS) {
+                    j.oth[offj + r] = wTH[(size_t)k * thstride + r];
+                    j.oix[offj + r] = wIX[(size_t)k * thstride + r];
+                }
+                off += cnt;
+                offj += cntj;
+            }
+            if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
+            return;
+        }
+        // fall through: the plain walk by wave 0
+    }
     if ((int)threadIdx.x < WAVE) {
         env_walk_wave(e, j.npts);
         *err = e.err;
@@ -1656,6 +1793,8 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     job.evfa0 = (const eg_ldsd *)s_evfa0;
     job.stack = (eg_ldsi *)s_stack;
     job.dbg = b.dbg + 16 * draw;
+    job.noseg = b.noseg;
+    job.segstat = b.segstat + 2 * (size_t)draw;
     job.klog = nullptr, job.kcnt = nullptr, job.kcap = b.kcap;
     if (b.klog) {  // third output of the solver gateway requested (egdst_set_dbgout): this cell's slice of the log
         const size_t kc = ((size_t)it * b.g.ndraw + draw) * MS_NST + ist;
@@ -1910,6 +2049,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             if (s_oob) ENV_FAIL(2704);
             {
                 int we = 0, wn = 0, wm = 0;
+                job.wM = qM, job.wV = qV, job.wC = qC, job.wcap = (int)W;   // (the global sort arrays are idle on this path)
                 run_walk<true>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm, fused);  // sorted M, C, V
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
@@ -1929,6 +2069,8 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             if (s_oob) ENV_FAIL(2714);
             {
                 int we = 0, wn = 0, wm = 0;
+                // (the unsorted input of a secondary envelope is dead once it is sorted; the primary's input lives in p*)
+                job.wM = sM, job.wV = sV, job.wC = sC, job.wcap = (int)W;
                 run_walk<false>(&E, job, qM, qC, qV, qF, rank, gcls, &we, &wn, &wm, fused);
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }

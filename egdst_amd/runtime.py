@@ -33,7 +33,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
                'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments',
                'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited', 'egdst_simulate_batch_moments',
-               'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout']
+               'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout', 'egdst_get_walk_stats']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -210,6 +210,12 @@ class Solver:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self.lib.check(self.lib.lib.egdst_get_schedule(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def walk_stats(self):
+        """[ndraw, 2]: envelope walks cut into segments and merged / fallen back to one wave (egdst_get_walk_stats)"""
+        out = np.zeros((self.ndraw, 2), dtype=np.uint32)
+        self.lib.check(self.lib.lib.egdst_get_walk_stats(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def work(self):
         """re-basing calls per draw in the last solve (egdst_get_work)"""

@@ -216,6 +216,11 @@ int egdst_get_checksums(egdst_handle *h, int draw, unsigned long long *out /* [n
  * include/egdst_math.h restates glibc's algorithms so that these equal the host libm bit for bit. */
 int egdst_math_eval(int fn, int n, const double *x, const double *y, double *out);
 
+/* Envelope walks of the last solve per draw: out[2*draw] = walks that were cut into segments (one wave each) and merged,
+ * out[2*draw+1] = walks whose segment predictions failed the check and were redone by one wave (results are the same
+ * either way; environment EGDST_NOSEG=1 at create turns the cutting off). */
+int egdst_get_walk_stats(egdst_handle *h, unsigned *out /* [2*ndraw] */);
+
 /* Raw device views for callers that keep data resident (bench, estimation loops). */
 int egdst_device_tables(egdst_handle *h, int it, const double **M_dev, const double **C_dev, const double **V_dev,
                         const int **len_dev);

@@ -17,7 +17,7 @@ def build(spec_dir, sanitize=True, env_bs=1, parallel_blocks=False, wave=1, fix_
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
         return out
     cmd = ['g++', '-x', 'c++', '-std=c++17', '-O1', '-g', '-mfma', '-ffp-contract=off', '-fPIC', '-shared',
-           '-DEGDST_EMU', '-DWAVE=%d' % wave, '-DGRID_BS=1', '-DENV_BS_EMU=%d' % env_bs, '-DFIX_BS=%d' % (1 if parallel_blocks else fix_waves * wave), '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
+           '-DEGDST_EMU', '-DENV_SEG_MINPTS=%d' % (4 * wave), '-DWAVE=%d' % wave, '-DGRID_BS=1', '-DENV_BS_EMU=%d' % env_bs, '-DFIX_BS=%d' % (1 if parallel_blocks else fix_waves * wave), '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
            '-Wno-unused-function', os.path.join(CSRC, 'egdst_kernels.hip'), '-o', out]
     if os.environ.get('EMU_SEQ_WALK'):
         cmd[1:1] = ['-DEGDST_SEQ_WALK']

@@ -484,3 +484,25 @@ def test_continuous_state_model_solver_simulator_accessor():
     from call_cases import call_cases
     for sw, args in call_cases(m, s.nt, s.lib.info.nst, s.lib.info.nd):
         assert np.array_equal(s.call(sw, args), orc.call(ref, sw, args), equal_nan=True), sw
+
+
+def test_segmented_envelope_walks_are_used_and_exact(monkeypatch):
+    """The envelope walk of a cell is cut at predictable points into one segment per wave, the predictions are checked
+    and the segments merged (run_walk in egdst_kernels.hip); EGDST_NOSEG=1 keeps the one-wave walk.  Both ways equal the
+    oracle bit for bit (C2 and C3 at full size: LDS-resident and global-memory streams), the statistics show that the
+    cutting really happens, and fallbacks (a failed prediction is not an error) stay rare."""
+    for name in ('C2', 'occ3_n1400_global_path'):
+        m = SCALED[name]()
+        ref = Oracle(m).solve()
+        for noseg in ('0', '1'):
+            monkeypatch.setenv('EGDST_NOSEG', noseg)
+            s = gpu_solve(m)
+            sol = s.solution(0)
+            ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+            assert ok and sol.nevals == ref.nevals, (name, noseg, rep)
+            merged, fallback = s.walk_stats()[0]
+            if noseg == '1':
+                assert merged == 0 and fallback == 0
+            else:
+                assert merged >= sol.nt // 2 and fallback <= merged // 4, (name, merged, fallback)
+            s.close()
