@@ -1463,6 +1463,9 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
 #define ENV_MAXSEG 8            // segments of a walk (one wave each)
 #define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per segment
 #define ENV_SEGNF 126           // functions a segmented walk can handle (2*(nf+2) stack entries per slice)
+#ifndef ENV_SEG_EVENT_COST
+#define ENV_SEG_EVENT_COST 320  // what a crossing costs the walk, in regular positions (~5 batches of 64)
+#endif
 #ifndef ENV_SEG_MINPTS
 #define ENV_SEG_MINPTS 192      // sorted points per segment below which cutting a walk is not worth it
 #endif
@@ -1479,6 +1482,7 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
     int *dbg;
     int noseg;     // 1: never cut the walk into segments (EGDST_NOSEG; tests compare both ways)
     unsigned *segstat;  // [2] of the draw: segmented walks merged / fallen back
+    int *sh;            // the workgroup's LDS scratch for scans ([ENV_MAXBS] ints)
     double *wM, *wV, *wC;  // scratch rows for the segments of a cut walk ([wcap] each; work arrays that are free while walking)
     int wcap;
     double *klog;  // kink log of the cell (dbgout), or nullptr
@@ -1597,10 +1601,56 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     }
 #endif
     if (nseg > 1) {
-        // cuts: the first position at or after s*npts/nseg whose point nothing lies above (and which is below the bound:
+        // Where to cut: segments of equal COST, not of equal length.  A regular stretch costs ~1/64 of a batch per position,
+        // a crossing several batches, and crossings cluster (the folds of a choice list sit in a narrow range of M).  The
+        // number of crossings in a stretch is estimated by how often the function of consecutive points that nothing lies
+        // above changes: every thread counts that in a chunk of the stream, a block-wide prefix sum of
+        // (positions + ENV_SEG_EVENT_COST * changes) follows, and cut k goes to the chunk where it passes k/nseg of the total.
+        __shared__ int sg_w[ENV_MAXBS / WAVE + 1];
+        int *const sg_a = j.sh;  // (the workgroup's scan scratch, [ENV_MAXBS])
+        const int C = (j.npts + ENV_BS - 1) / ENV_BS;
+        int ff = -1, lf = -1, sw = 0;
+        {
+            const int qa = tid_ * C, qb = min(j.npts, qa + C);
+            for (int q = qa; q < qb; q++) {
+                const int w = cls[q];
+                if (w >= 0 && !(w & 1)) {
+                    const int fq = (int)f[q];
+                    if (lf >= 0 && fq != lf) sw++;
+                    if (ff < 0) ff = fq;
+                    lf = fq;
+                }
+            }
+        }
+        sg_a[tid_] = lf;
+        if (tid_ <= ENV_MAXSEG) sg_p[tid_] = -1;
+        __syncthreads();
+        if (tid_ > 0 && ff >= 0 && sg_a[tid_ - 1] >= 0 && sg_a[tid_ - 1] != ff) sw++;  // (a change across the chunk border)
+        int cost = min(C, max(0, j.npts - tid_ * C)) + ENV_SEG_EVENT_COST * sw, incl = cost;
+        for (int o = 1; o < WAVE; o <<= 1) {  // inclusive prefix sum over the wave, then over the waves
+            const int t = __shfl_up(incl, o);
+            if (lane_ >= o) incl += t;
+        }
+        __syncthreads();
+        if (lane_ == WAVE - 1) sg_w[wave_] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < ENV_BS / WAVE; w++) {
+            if (w < wave_) before += sg_w[w];
+            total += sg_w[w];
+        }
+        incl += before;
+        for (int k = 1; k < nseg; k++) {  // the chunk in which the running cost passes k/nseg of the total
+            const long long thr = (long long)total * k / nseg;
+            if (incl - cost < thr && thr <= incl) sg_p[k] = min(tid_ * C, j.npts - 1);
+        }
+        if (tid_ < nseg && total <= 0) sg_p[tid_] = -1;
+        __syncthreads();
+        // cuts: the first position at or after the target whose point nothing lies above (and which is below the bound:
         // such class words are never negative); one lane per cut, then thread 0 keeps the increasing ones
         if (tid_ >= 1 && tid_ < nseg) {
-            int q = (int)((long long)tid_ * j.npts / nseg);
+            int q = sg_p[tid_];
+            if (q < 0) q = j.npts;
             const int lim = min(j.npts - 2, q + 6 * WAVE);
             while (q < lim && (cls[q] < 0 || (cls[q] & 1))) q++;
             sg_p[tid_] = (q < lim) ? q + 1 : -1;
@@ -1611,7 +1661,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             sg_p[0] = 0;
             for (int k = 1; k < nseg; k++) {
                 const int pk = sg_p[k];
-                if (pk > prev + WAVE) sg_p[n++] = pk, prev = pk;
+                if (pk > prev + WAVE / 4) sg_p[n++] = pk, prev = pk;
             }
             sg_p[n] = j.npts;
             sg_n = n;
@@ -1621,25 +1671,24 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     }
     if (nseg > 1) {
         double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
-        if (wave_ < nseg) {
-            EnvCtxT<L> es = e;
+        if (wave_ < nseg) {  // (every thread owns a copy of the context: a wave points its own at its segment)
             const int sgi = wave_, p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
             const size_t row0 = 2 * (size_t)p0 + 64 * (size_t)sgi;
-            es.cur = j.cur + sgi * ENV_SEGNF_SLICE;
-            es.mark = j.mark + sgi * ENV_SEGNF_SLICE;
-            es.stack = j.stack + sgi * 2 * ENV_SEGNF_SLICE;
-            es.stackcap = 2 * ENV_SEGNF_SLICE;
-            es.og = j.wM + row0, es.ov = j.wV + row0, es.oc = j.wC + row0;
-            es.ocap = 2 * (p1 - p0) + 64;
-            es.oth = wTH + (size_t)sgi * thstride, es.oix = wIX + (size_t)sgi * thstride;
-            es.nthrhmax = thstride;
+            e.cur = j.cur + sgi * ENV_SEGNF_SLICE;
+            e.mark = j.mark + sgi * ENV_SEGNF_SLICE;
+            e.stack = j.stack + sgi * 2 * ENV_SEGNF_SLICE;
+            e.stackcap = 2 * ENV_SEGNF_SLICE;
+            e.og = j.wM + row0, e.ov = j.wV + row0, e.oc = j.wC + row0;
+            e.ocap = 2 * (p1 - p0) + 64;
+            e.oth = wTH + (size_t)sgi * thstride, e.oix = wIX + (size_t)sgi * thstride;
+            e.nthrhmax = thstride;
             int pm0 = -1;
             double lastg0 = 0;
             if (sgi > 0) pm0 = (int)f[p0 - 1], lastg0 = m[p0 - 1];
 #ifdef EGDST_STAMPS
             const unsigned long long sgt0_ = wall_clock64();
 #endif
-            env_walk_wave(es, j.npts, p0, p1, sgi > 0 ? 1 : 0, pm0, lastg0);
+            env_walk_wave(e, j.npts, p0, p1, sgi > 0 ? 1 : 0, pm0, lastg0);
 #ifdef EGDST_STAMPS
             if (lane_ == 0 && j.dbg) {  // diagnostic: longest segment (slot 0) and sum over segments (slot 1, was: classification)
                 const unsigned long long d_ = wall_clock64() - sgt0_;
@@ -1648,8 +1697,8 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             }
 #endif
             if (lane_ == 0) {
-                sg_oi[sgi] = es.oi, sg_oj[sgi] = es.oj, sg_err[sgi] = es.err, sg_pm[sgi] = es.pm;
-                sg_lastg[sgi] = es.lastg;
+                sg_oi[sgi] = e.oi, sg_oj[sgi] = e.oj, sg_err[sgi] = e.err, sg_pm[sgi] = e.pm;
+                sg_lastg[sgi] = e.lastg;
             }
         }
         __syncthreads();
@@ -1690,7 +1739,10 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
             return;
         }
-        // fall through: the plain walk by wave 0
+        // fall through: the plain walk by wave 0, from the job's own arrays again
+        e.cur = j.cur, e.mark = j.mark, e.stack = j.stack, e.stackcap = j.stackcap;
+        e.og = j.og, e.ov = j.ov, e.oc = j.oc, e.oth = j.oth, e.oix = j.oix;
+        e.ocap = j.ocap, e.nthrhmax = j.nthrhmax, e.err = 0;
     }
     if ((int)threadIdx.x < WAVE) {
         env_walk_wave(e, j.npts);
@@ -1794,6 +1846,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     job.stack = (eg_ldsi *)s_stack;
     job.dbg = b.dbg + 16 * draw;
     job.noseg = b.noseg;
+    job.sh = sh;
     job.segstat = b.segstat + 2 * (size_t)draw;
     job.klog = nullptr, job.kcnt = nullptr, job.kcap = b.kcap;
     if (b.klog) {  // third output of the solver gateway requested (egdst_set_dbgout): this cell's slice of the log
