@@ -1177,8 +1177,20 @@ static __device__ __forceinline__ bool pt_before(double am, double av, int af, i
 // Rank of point i = (m, v, f) among npts points of nf functions whose lists are in comp1 order: the sum over the
 // functions of "how many of its points precede this one".  The same counts give the walk's class word of the point
 // (env_preclass): evaluated right here when cls_on.  KP: pointer type of the keys (LDS-staged or global).
-template <class KP, class ANA>
-static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KP Kv, int f, double m, double v, const eg_ldsi *fstart,
+// pt_before for a key that lives in two arrays: the V key is read only when the M keys tie
+template <class KP, class KPV>
+static __device__ __forceinline__ bool eg_key_before(KP Km, KPV Kv, int k, int g, double m, double v, int f, int i)
+{
+    const double am = Km[k];
+    if (am != m) return am < m;
+    const double av = Kv[k];
+    if (av != v) return av > v;
+    if (g != f) return g < f;
+    return k < i;
+}
+
+template <class KP, class KPV, class ANA>
+static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KPV Kv, int f, double m, double v, const eg_ldsi *fstart,
                                                        const eg_ldsi *dims, bool cls_on, double kbound, ANA ana, int *w_out)
 {
     int r = 0, w = 0;
@@ -1194,17 +1206,17 @@ static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KP 
         // lo = points of g that precede this one.  Most lists lie entirely on one side of the point (pieces of a
         // folded choice list overlap only near the kinks), which two or three key reads settle
         int lo = 0;
-        if (pt_before(Km[s0], Kv[s0], g, s0, m, v, f, i)) {
-            if (pt_before(Km[s0 + dg - 1], Kv[s0 + dg - 1], g, s0 + dg - 1, m, v, f, i))
+        if (eg_key_before(Km, Kv, s0, g, m, v, f, i)) {
+            if (eg_key_before(Km, Kv, s0 + dg - 1, g, m, v, f, i))
                 lo = dg;
-            else if (dg >= 2 && pt_before(Km[s0 + dg - 2], Kv[s0 + dg - 2], g, s0 + dg - 2, m, v, f, i))
+            else if (dg >= 2 && eg_key_before(Km, Kv, s0 + dg - 2, g, m, v, f, i))
                 lo = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
             else {
                 int hi = dg >= 2 ? dg - 2 : dg - 1;
                 lo = 1;
                 while (lo < hi) {  // first position in [lo, hi] that does not precede the point
                     const int mid = (lo + hi) >> 1;
-                    if (pt_before(Km[s0 + mid], Kv[s0 + mid], g, s0 + mid, m, v, f, i))
+                    if (eg_key_before(Km, Kv, s0 + mid, g, m, v, f, i))
                         lo = mid + 1;
                     else
                         hi = mid;
@@ -1248,8 +1260,18 @@ static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KP 
 template <class ANA>
 static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const double *im, const double *ic, const double *iv, const int *ifn,
                                      const eg_ldsi *fstart, const eg_ldsi *dims, double *om, double *oc, double *ov, int *of,
-                                     int *rank, int *sh, int *oob, int *dbg, int *cls, int *fused, ANA ana)
+                                     int *rank, int *sh, int *oob, int *dbg, int *cls, int *fused, ANA ana, eg_ldsd *lkeys,
+                                     int lkeys_cap)
 {
+    // lkeys: the workgroup's dynamic LDS, lkeys_cap doubles.  A stream that is too long to be sorted and walked in LDS
+    // (32 B per point) often still fits with its M keys alone (8 B per point: C3's 12 000-point primary stream, 96 KB):
+    // the binary searches of the rank merge then run on LDS, and the V keys are read from global memory only at M ties
+    // and at the bracket of the classification.
+    const bool lds_keys = lkeys != nullptr && npts <= lkeys_cap;
+    if (lds_keys) {
+        for (int i = threadIdx.x; i < npts; i += ENV_BS) lkeys[i] = im[i];
+        __syncthreads();
+    }
     int bad = 0;
     for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
         if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
@@ -1270,7 +1292,10 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         int r = 0;
         if (!bad) {
             int w = 0;
-            r = eg_rank_classify(i, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
+            if (lds_keys)
+                r = eg_rank_classify(i, nf, (const eg_ldsd *)lkeys, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
+            else
+                r = eg_rank_classify(i, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
             if (cls && r >= 0 && r < npts) cls[r] = w;
         } else {
             for (int j = 0; j < npts; j++)
@@ -2118,7 +2143,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
         } else {
             int *gcls = b.gcls + wo;  // class words of the sorted stream
             blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg, gcls, &fused,
-                          ana);
+                          ana, R1, 4 * lcap);
             if (s_oob) ENV_FAIL(2714);
             {
                 int we = 0, wn = 0, wm = 0;
