@@ -61,7 +61,11 @@ struct Batch {
     int *rank;                          // [W] sorted position of each input point
     int *gcls;                          // [W] class words of a stream that is sorted in global memory
     double *eM, *eV, *eC;               // [Cp] output of a secondary envelope
-    double *eTH, *eIX;                  // [Cp]
+    double *eTH, *eIX;                  // [MS_ND][nthrhmax] thresholds of a secondary envelope (not used afterwards)
+    // hand-over from the per-choice workgroups of k_envelope (part 1) to the primary envelope (part 2), per (cell, choice):
+    int *secn, *secact, *secerr;        // rows of the choice's list, choice active, first error of the job
+    double *secev;                      // expected value at a0 of the choice
+    unsigned long long *secevals;       // evaluations counted by the job
     // status
     int *status;          // [ndraw] first error code
     int *where;           // [2*ndraw] (it, ist) of that error

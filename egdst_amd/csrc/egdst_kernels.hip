@@ -1477,13 +1477,17 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
 
 // ---------------------------------------------------------------------------------------------
 // Stop rule, compaction, secondary and primary envelopes, output rows for one (draw, ist).
-#define ENV_FAIL(code)                                   \
-    do {                                                 \
-        if (tid == 0) {                                  \
-            eg_fail(b, draw, it, ist, (code));           \
-            b.tlen[tk] = b.tthlen[tk] = 0;               \
-        }                                                \
-        return;                                          \
+#define ENV_FAIL(code)                                                                    \
+    do {                                                                                  \
+        if (tid == 0) {                                                                   \
+            if (part == 1) /* part 2 reports the first error of the cell in choice order */ \
+                b.secerr[cell * MS_ND + pid] = (code);                                    \
+            else {                                                                        \
+                eg_fail(b, draw, it, ist, (code));                                        \
+                b.tlen[tk] = b.tthlen[tk] = 0;                                            \
+            }                                                                             \
+        }                                                                                 \
+        return;                                                                           \
     } while (0)
 #define ENV_MAXSEG 8            // segments of a walk (one wave each)
 #define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per segment
@@ -1784,7 +1788,11 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifndef ENV_MINW
 #define ENV_MINW 1
 #endif
-__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass)
+// part: 0 the whole cell in one workgroup (jobs one after another);  1 / 2 (models with several choices): the choice lists
+//       and their secondary envelopes as workgroups of their own, one per (cell, choice) -- they are independent of each
+//       other (egdst_solver.c:668: envelope2 per id) -- and then the primary envelope per cell.  The lists of part 1 live in
+//       per-choice slices of the cell's work arrays; what part 2 needs besides them is handed over in Batch.sec*.
+__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
 {
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_MAXBS];
@@ -1793,18 +1801,26 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
-    const int ist = blockIdx.x % MS_NST, draw = b.order[b.draw0 + blockIdx.x / MS_NST];
+    const int bx_ = (part == 1) ? (int)blockIdx.x / MS_ND : (int)blockIdx.x, pid = (part == 1) ? (int)blockIdx.x % MS_ND : 0;
+    const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
     const size_t cell = (size_t)draw * MS_NST + ist;
+    if (part == 1 && tid == 0) {  // (whatever happens below, part 2 finds a record)
+        b.secn[cell * MS_ND + pid] = 0;
+        b.secact[cell * MS_ND + pid] = 0;
+        b.secerr[cell * MS_ND + pid] = 0;
+        b.secev[cell * MS_ND + pid] = 0.0;
+        b.secevals[cell * MS_ND + pid] = 0ull;
+    }
     if (pass == 1) {
         if (!b.defer[cell]) return;  // done in pass 0
         __syncthreads();
         if (tid == 0) b.defer[cell] = 0;
     }
     if (b.status[draw]) {
-        if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        if (tid == 0 && part != 1) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
     }
     ms_env E = eg_env(b, draw);
@@ -1814,7 +1830,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     cur.id = 0;
     cur.cash = cur.savings = cur.shock = 0;
     if (ms_feasible(&E, &cur) != 1) {
-        if (tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
+        if (tid == 0 && part != 1) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
     }
     // Rows of this cell that may hold non-zero leftovers of an earlier period (ping-pong slots) or of an earlier
@@ -1823,11 +1839,13 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     // (egdst_solver.c:198-217): the rows past the new length are zeroed below to keep exactly that.
     const int hw_rows = b.thw[tk], hw_th = b.thhw[tk];
     __syncthreads();
-    if (tid == 0) b.thw[tk] = b.g.Sp, b.thhw[tk] = b.g.nthrhmax;  // until this cell is complete: unknown
+    if (tid == 0 && part != 1) b.thw[tk] = b.g.Sp, b.thhw[tk] = b.g.nthrhmax;  // until this cell is complete: unknown
     const int ngridmax = b.g.ngridmax, ngridm = b.g.ngridm;
     const double mmax = b.g.mmax;
     const int compact = b.g.Cp < ngridmax;  // physical capacity below the logical one: overflow = EGDST_E_CAPACITY
-    const size_t W = (size_t)(MS_ND + 1) * b.g.Cp, wo = ((size_t)draw * MS_NST + ist) * W;
+    // part 1 works in the slice [pid*Cp, (pid+1)*Cp) of the cell's work arrays (W then means that slice)
+    const size_t Wcell = (size_t)(MS_ND + 1) * b.g.Cp, W = (part == 1) ? (size_t)b.g.Cp : Wcell;
+    const size_t wo = ((size_t)draw * MS_NST + ist) * Wcell + (size_t)pid * b.g.Cp;
     double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
     int *pF = b.pF + wo;
     double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
@@ -1835,8 +1853,10 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
     int *qF = b.qF + wo, *rank = b.rank + wo;
     const size_t eo = ((size_t)draw * MS_NST + ist) * (size_t)b.g.Cp;
-    const size_t eto = ((size_t)draw * MS_NST + ist) * (size_t)b.g.nthrhmax;
-    double *eM = b.eM + eo, *eV = b.eV + eo, *eC = b.eC + eo, *eTH = b.eTH + eto, *eIX = b.eIX + eto;
+    const size_t eto = (((size_t)draw * MS_NST + ist) * MS_ND + pid) * (size_t)b.g.nthrhmax;
+    // (part 1: the secondary envelope writes its result over the choice list it came from, which is dead by then)
+    double *eM = (part == 1) ? pM : b.eM + eo, *eV = (part == 1) ? pV : b.eV + eo, *eC = (part == 1) ? pC : b.eC + eo;
+    double *eTH = b.eTH + eto, *eIX = b.eIX + eto;
     double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
     double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
     // typed LDS views
@@ -1875,7 +1895,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     job.segstat = b.segstat + 2 * (size_t)draw;
     job.klog = nullptr, job.kcnt = nullptr, job.kcap = b.kcap;
     if (b.klog) {  // third output of the solver gateway requested (egdst_set_dbgout): this cell's slice of the log
-        const size_t kc = ((size_t)it * b.g.ndraw + draw) * MS_NST + ist;
+        const size_t kc = ((size_t)it * b.g.ndraw + draw) * MS_NST + ist;   // (the host launches part 0 when the log is on)
         job.klog = b.klog + kc * 4 * (size_t)b.kcap;
         job.kcnt = b.kcnt + kc;
         if (tid == 0) *job.kcnt = 0;
@@ -1900,7 +1920,43 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
     unsigned long long evals = 0;
     // jobs 0..MS_ND-1: the list of one choice (stop rule, compaction, secondary envelope when it folds back);
     // job MS_ND: the primary envelope across choices.  Sorting and walking is ONE code site for all of them.
-    for (int jb = 0; jb <= MS_ND && !done; jb++) {
+    int part_eff = part;
+    if (part == 2) {
+        // the choice lists of part 1: first error in choice order, then the lists packed one after another at the front
+        // of the cell's arrays (choice 0's slice starts there already; a later list moves down, never past its own start)
+        // (a list or its pieces did not fit the slice of the cell's arrays -- a degenerate guess stream with ~ngridmax
+        // points: this workgroup then does the whole cell again, one job after the other, in the full arrays)
+        int err2 = 0;
+        for (int k = 0; k < MS_ND; k++)
+            if (b.secerr[cell * MS_ND + k] == -1) part_eff = 0;
+        for (int k = 0; k < MS_ND && !err2 && part_eff; k++) err2 = b.secerr[cell * MS_ND + k];
+        if (err2) ENV_FAIL(err2);
+        for (int k = 0; k < MS_ND && part_eff; k++) {
+            evals += b.secevals[cell * MS_ND + k];
+            const int cntk = b.secn[cell * MS_ND + k];
+            if (b.secact[cell * MS_ND + k]) any = 1;
+            if (tid == 0) {
+                s_cnt[k] = cntk;
+                s_start[k] = nall;
+                s_evfa0[k] = b.secev[cell * MS_ND + k];
+            }
+            const size_t src = (size_t)k * b.g.Cp;
+            if (k > 0 && cntk > 0) {
+                for (int base = 0; base < cntk; base += ENV_BS) {  // (chunks: read, barrier, write -- the ranges may overlap)
+                    const int r = base + tid;
+                    double a_ = 0, b2_ = 0, c_ = 0;
+                    if (r < cntk) a_ = pM[src + r], b2_ = pC[src + r], c_ = pV[src + r];
+                    __syncthreads();
+                    if (r < cntk) pM[nall + r] = a_, pC[nall + r] = b2_, pV[nall + r] = c_;
+                    __syncthreads();
+                }
+            }
+            for (int r = tid; r < cntk; r += ENV_BS) pF[nall + r] = k;
+            nall += cntk;
+        }
+        __syncthreads();
+    }
+    for (int jb = (part_eff == 2 ? MS_ND : (part_eff == 1 ? pid : 0)); jb <= (part_eff == 1 ? pid : MS_ND) && !done; jb++) {
         const bool primary = (jb == MS_ND);
         const int id = jb;
         const double *iM, *iC, *iV;
@@ -1986,7 +2042,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             }
             __syncthreads();
             STAMP(0);  // stop rule + compaction
-            if (s_oob) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2705);
+            if (s_oob) ENV_FAIL(part == 1 ? -1 : (compact ? EGDST_E_CAPACITY : 2705));  // (-1: see part 2)
             // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -----------
             int nfold = 0;
             if (!terminal && cnt > 1) {
@@ -2035,7 +2091,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
                 carry += tot;
             }
             lastfold = blk_sum(lastfold, sh);
-            if (s_oob) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2706);
+            if (s_oob) ENV_FAIL(part == 1 ? -1 : (compact ? EGDST_E_CAPACITY : 2706));
             if (lastfold + (nfold - 1) >= ngridmax) ENV_FAIL(17);
             if (id + nfold >= 10000) ENV_FAIL(18);
             job.npts = cnt + nfold;
@@ -2159,7 +2215,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
         if (!primary) {
             if (s_n >= ngridmax) ENV_FAIL(17);  // (:884)
             cnt = s_n;
-            if ((size_t)(nall + cnt) > W) ENV_FAIL(compact ? EGDST_E_CAPACITY : 2705);
+            if ((size_t)(nall + cnt) > W) ENV_FAIL(part == 1 ? -1 : (compact ? EGDST_E_CAPACITY : 2705));
             for (int i = tid; i < cnt; i += ENV_BS) {
                 pM[nall + i] = eM[i];
                 pC[nall + i] = eC[i];
@@ -2177,6 +2233,16 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             outn = s_n;
             outm = s_m;
         }
+    }
+    if (part == 1) {  // hand the choice's list over to part 2
+        __syncthreads();
+        if (tid == 0) {
+            b.secn[cell * MS_ND + pid] = s_cnt[pid];
+            b.secev[cell * MS_ND + pid] = s_evfa0[pid];
+            b.secact[cell * MS_ND + pid] = any;
+            b.secevals[cell * MS_ND + pid] = evals;
+        }
+        return;
     }
     for (int i = outn + 1 + tid; i < hw_rows; i += ENV_BS) oM[i] = oC[i] = oV[i] = 0.0;
     for (int i = outm + tid; i < hw_th; i += ENV_BS) oTH[i] = oD[i] = 0.0;
