@@ -174,6 +174,7 @@ def main():
     mine_n = hi - lo
     chunk = args.chunk or DEFAULT_CHUNK.get(args.workload, 256)
     chunk = max(1, min(chunk, max(mine_n, 1)))
+    plan = parallel.plan_chunks(mine_n, chunk)     # [(first draw of the shard, draws that count)] per chunk
     nsteps_all = args.warmup + args.steps
 
     def step_draws(s):
@@ -187,7 +188,7 @@ def main():
 
     host_draws = [step_draws(s) for s in range(nsteps_all)]
     # inputs resident in HBM before the timed region: [step][draw][param], padded to whole chunks with the shard's first draw
-    nchunks = (mine_n + chunk - 1) // chunk if mine_n else 0
+    nchunks = len(plan)
     padded = nchunks * chunk
     dev = torch.zeros(nsteps_all, max(padded, 1), max(nparam, 1), dtype=torch.float64, device='cuda')
     for s, p in enumerate(host_draws):
@@ -209,11 +210,10 @@ def main():
     def run_step(s):
         """one step of this rank: every chunk of its shard through the one handle; returns the counters"""
         ev_ref = ev_exec = nfail = ndone = 0
-        for c in range(nchunks):
+        for c, (c0, valid) in enumerate(plan):                  # (the last chunk may be padded: valid < chunk)
             solver.set_params_dev(dev[s, c * chunk:(c + 1) * chunk].data_ptr())
             solver.solve_async()
             solver.sync(raise_on_error=False)
-            valid = min(chunk, mine_n - c * chunk)              # (the last chunk may be padded)
             st, _ = solver.status()
             per = solver.evals()[1]
             cred = solver.evals_credited()
@@ -320,6 +320,20 @@ def main():
                 out['single_solve_plus_export_ms'] = (time.perf_counter() - t1) * 1e3
                 out['export_bytes'] = int(sol.len.sum()) * 24 + int(sol.thlen.sum()) * 16
                 s2.close()
+        if not args.no_extras and not args.no_single_solve and world == 1 and args.workload == 'C2' and not args.small:
+            # SURVEY.md section 8d pins C2 on the shipped credit limit a0=-5 (the survey's probe: 1 180 889 evaluations); the
+            # headline runs a0=0 because with a0=-5 the reference algorithm itself writes a non-finite row at it=4
+            from egdst_amd import examples
+            m5 = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=-5)
+            s5 = runtime.Solver(build.build_model(m5), m5.descriptor(), ndraw=1, keep_history=False)
+            s5.set_params(m5.param_vector()[None])
+            s5.solve(raise_on_error=False)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                s5.solve(raise_on_error=False)
+            out['c2_shipped_a0_minus5'] = {'single_solve_ms': (time.perf_counter() - t1) / 3 * 1e3, 'evals': int(s5.evals()[0]),
+                                           'status': int(s5.status()[0][0])}
+            s5.close()
         if not args.no_extras and world == 1:
             # measured streaming-copy rate of this box (read + write), the practical HBM ceiling beside the 8 TB/s spec
             a = torch.empty(1 << 28, dtype=torch.float64, device='cuda')   # 2 GiB

@@ -17,6 +17,17 @@ def shard_bounds(ndraw, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def plan_chunks(ndraw_rank, chunk):
+    """How a rank walks its shard through ONE handle of `chunk` draws (bench.py --scaling strong): a list of
+    (first draw of the shard, draws that count) per chunk; the last chunk may be short -- the handle is then filled up
+    with copies of the shard's first draw, which are solved but not counted."""
+    ndraw_rank, chunk = int(ndraw_rank), int(chunk)
+    if ndraw_rank <= 0:
+        return []
+    chunk = max(1, min(chunk, ndraw_rank))
+    return [(c, min(chunk, ndraw_rank - c)) for c in range(0, ndraw_rank, chunk)]
+
+
 def reduce_objective(local_obj, ok_mask=None, group=None):
     """Sum and count of the finite per-draw objective contributions over all ranks.
 

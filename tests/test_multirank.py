@@ -25,6 +25,22 @@ def test_shard_bounds_cover_all_draws():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_strong_scaling_plan_covers_the_job_exactly_once():
+    """bench.py --scaling strong: the job's draws are split over the ranks (shard_bounds) and every rank walks its shard
+    in chunks through one handle (plan_chunks): every draw of the job is counted exactly once, whatever the sizes."""
+    for job, world, chunk in ((1024, 8, 128), (1024, 1, 128), (256, 8, 32), (1000, 3, 128), (5, 8, 128), (64, 2, 16), (130, 1, 128)):
+        seen = np.zeros(job, dtype=int)
+        for r in range(world):
+            lo, hi = parallel.shard_bounds(job, world, r)
+            plan = parallel.plan_chunks(hi - lo, chunk)
+            assert sum(v for _, v in plan) == hi - lo
+            for c0, valid in plan:
+                assert 0 < valid <= max(1, min(chunk, hi - lo))
+                seen[lo + c0:lo + c0 + valid] += 1
+        assert np.all(seen == 1), (job, world, chunk)
+    assert parallel.plan_chunks(0, 128) == []
+
+
 def _worker(rank, world, port, ndraw, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
