@@ -37,6 +37,7 @@ struct Batch {
     const int *order;    // [ndraw] schedule: slot -> draw (identity until the host re-balances, egdst_host.inc)
     struct Env1Scratch *e1sc;  // single-choice models: per (slot, state) scratch of the k_env1_* kernels
     int *e1first, *e1cnt;      // first stopping candidate; rows per workgroup [E1 workgroups per cell]
+    int *tsorted;        // [ndraw*MS_NST] the M column of the next-period table of (draw, state) is in order (k_sortcheck)
     int *negflag;        // [(draw*MS_NST+ist)*MS_ND+id] a grid point of the stream signalled c1<=0 (set by k_grid)
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot

@@ -904,10 +904,101 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
     return c1;
 }
 
+// The same for tables that are too long for LDS (C4: 65 537 rows, C5: 4 x 32 769): every `stride`-th row of the M column
+// is staged (a sampled index), the bracket search runs on the sample in LDS and is finished by log2(stride) steps in the
+// window of the global column between two samples (one or two cache lines) -- 3-5 dependent global loads per evaluation
+// instead of 2 x 16.  The column must be in order (k_sortcheck, once per table); `edge` holds M[1], M[2], M[len-2], M[len-1].
+static __device__ __forceinline__ int eg_bracket_sampled(double x, const eg_ldsd *S, int ns, int stride, const double *M, int n1,
+                                                         const eg_ldsd *edge)
+{
+    if (x < edge[0]) return 0;
+    if (x >= edge[2]) return n1 - 2;
+    int lo = 0, hi = ns;  // S[0] = M[0] <= M[1] <= x
+    while (hi - lo > 1) {
+        const int mid = (hi + lo) >> 1;
+        if (S[mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    int a = lo * stride, z = min(a + stride, n1 - 2);  // M[a] <= x < M[z]
+    while (z - a > 1) {
+        const int mid = (z + a) >> 1;
+        if (M[mid] <= x)
+            a = mid;
+        else
+            z = mid;
+    }
+    return a;
+}
+
+static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const eg_ldsd *S, int ns, int stride, const eg_ldsd *edge,
+                                                         const Tab &t, const ms_pv *cur, ms_pv *nxt, double pr1, double *t_rhs,
+                                                         double *t_evf)
+{
+    nxt->cash = ms_cashinhand(E, cur, nxt);
+    const double x = nxt->cash;
+    const int n1 = t.len;
+    const int i = eg_bracket_sampled(x, S, ns, stride, t.M, n1, edge);
+    const double mlast = edge[3], mfirst = edge[0];
+    double c1 = eg_lerp(x, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
+    if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
+    *t_rhs = 0;
+    *t_evf = 0;
+    if (c1 <= 0) return c1;
+    if (!MS_OPTIM_MUNOD || (!MS_OPTIM_UNOD && x < mfirst))
+        nxt->id = (int)t.D[eg_bracket(x, t.TH, t.thlen, 1)];  // optimd, egdst_lib.c:129-132
+    else
+        nxt->id = 0;
+    *t_rhs = pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
+    const double evf1 = t.V[0], a0 = E->a0;
+    double val;
+    if (x < mfirst && evf1 > -INFINITY)
+        val = ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
+    else {
+        const int j = eg_second_bracket(x, i, edge[1], edge[2], n1);  // == eg_bracket(x, M + 1, n1 - 1, 0)
+        const double f0 = t.V[j + 1], f1 = t.V[j + 2];
+        if (!isfinite(f0))
+            val = f0;
+        else if (!isfinite(f1))
+            val = f1;
+        else {
+            const double g0 = t.M[j + 1], g1 = t.M[j + 2];
+            if (x > a0 && (x > mlast || x < mfirst)) {
+                const double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
+                val = f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
+            } else
+                val = eg_lerp(x, g0, g1, f0, f1);
+        }
+    }
+    *t_evf = pr1 * val;
+    return c1;
+}
+
+// Is the M column of every next-period table non-decreasing?  One workgroup per (draw, state) of the group, once per
+// period, for the handles whose tables do not fit k_grid_lds' LDS (the staged form checks the order while staging).
+__global__ void __launch_bounds__(GRID_BS) k_sortcheck(Batch b, int it)
+{
+    __shared__ int bad_;
+    const int ist = blockIdx.x % MS_NST, draw = b.order[b.draw0 + blockIdx.x / MS_NST];
+    const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+    const Tab t = eg_tab(b, slot1, draw, ist);
+    if (threadIdx.x == 0) bad_ = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int r = threadIdx.x; r + 1 < t.len; r += GRID_BS)
+        if (!(t.M[r] <= t.M[r + 1])) bad = 1;
+    if (bad) bad_ = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) b.tsorted[(size_t)draw * MS_NST + ist] = (t.len >= 4 && t.len <= b.g.Sp && !bad_) ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows)
 {
     EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
     __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded
+    __shared__ int gl_stride, gl_ns[MS_NST];  // every gl_stride-th row is staged (1: whole columns); staged entries per state
+    __shared__ double gl_edge[MS_NST * 4];    // M[1], M[2], M[len-2], M[len-1] of every staged table
     __shared__ double gl_shock[MS_SHOCK_NODES_SHARED ? MS_NST * EG_GRID_NYMAX : 1];
     __shared__ int gl_niy[MS_NST];
     const int combo = blockIdx.y;
@@ -935,18 +1026,59 @@ __global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows
             if (ms_feasible(&E, &nx) != 1) continue;
             const size_t k = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + nx.ist;
             const int len = b.tlen[k];
-            if (len < 4 || len > b.g.Sp || tot + len > lrows) {  // (short or missing tables: the general path reports them)
+            if (len < 4 || len > b.g.Sp) {  // (short or missing tables: the general path reports them)
                 ok = 0;
                 break;
             }
-            gl_off[nx.ist] = tot;
+            gl_off[nx.ist] = len;  // (rows for now; offsets below)
             tot += len;
         }
+        int stride = 1;
+        if (ok && tot > lrows) {
+            // too long: a sampled index of every column; needs the tables in order (k_sortcheck ran before this kernel)
+            int nfe = 0;
+            for (int s1 = 0; s1 < MS_NST; s1++) nfe += gl_off[s1] > 0;
+            stride = (tot + lrows - nfe - 1) / max(lrows - nfe, 1);
+            for (int s1 = 0; s1 < MS_NST && ok; s1++)
+                if (gl_off[s1] > 0 && !b.tsorted[(size_t)draw * MS_NST + s1]) ok = 0;
+        }
+        int acc = 0;
+        for (int s1 = 0; s1 < MS_NST; s1++) {
+            const int len = gl_off[s1];
+            if (len <= 0) continue;
+            gl_ns[s1] = (len + stride - 1) / stride;
+            gl_off[s1] = acc;
+            acc += gl_ns[s1];
+        }
+        if (acc > lrows) ok = 0;
+        gl_stride = stride;
         gl_ok = ok;
     }
     __syncthreads();
     bool fast = gl_ok != 0;
-    if (fast) {
+    const int stride = gl_stride;
+    if (fast && stride > 1) {  // sampled index + the four edge values of every column (order checked by k_sortcheck)
+        ms_pv nx;
+        nx.it = it + 1, nx.id = 0, nx.cash = nx.shock = 0, nx.savings = 0;
+        for (int s1 = 0; s1 < MS_NST; s1++) {
+            const int off = gl_off[s1];
+            if (off < 0) continue;
+            const Tab t = eg_tab(b, slot1, draw, s1);
+            for (int k = threadIdx.x; k < gl_ns[s1]; k += GRID_BS) LM[off + k] = t.M[(size_t)k * stride];
+            if (threadIdx.x == 0) {
+                gl_edge[4 * s1] = t.M[1], gl_edge[4 * s1 + 1] = t.M[2];
+                gl_edge[4 * s1 + 2] = t.M[t.len - 2], gl_edge[4 * s1 + 3] = t.M[t.len - 1];
+            }
+            if (MS_SHOCK_NODES_SHARED) {
+                nx.ist = s1;
+                const int niy = (ms_sigma(&E, &cur, &nx) <= 0 || ny == 1) ? 1 : ny;
+                if (threadIdx.x == 0) gl_niy[s1] = niy;
+                for (int iy = threadIdx.x; iy < niy; iy += GRID_BS)
+                    gl_shock[s1 * EG_GRID_NYMAX + iy] = (niy == 1) ? eg_shock_mean(&E, &cur, &nx) : eg_shock_node(&E, &cur, &nx, b.qz[iy]);
+            }
+        }
+        __syncthreads();
+    } else if (fast) {
         int bad = 0;
         ms_pv nx;
         nx.it = it + 1, nx.id = 0, nx.cash = nx.shock = 0, nx.savings = 0;
@@ -1003,6 +1135,8 @@ __global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows
                 break;
             }
             const eg_ldsd *M = LM + gl_off[nxt.ist];
+            const int ns = gl_ns[nxt.ist];
+            const eg_ldsd *edge = (const eg_ldsd *)gl_edge + 4 * nxt.ist;
             for (int iy = 0; iy < niy; iy++) {
                 double pr1;
                 if (MS_SHOCK_NODES_SHARED)
@@ -1015,7 +1149,8 @@ __global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows
                 checksum += pr1;
                 cnt++;
                 double t_rhs, t_evf;
-                c1 = eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf);
+                c1 = (stride > 1) ? eg_term_sampled(&E, M, ns, stride, edge, t, &cur, &nxt, pr1, &t_rhs, &t_evf)
+                                  : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf);
                 if (c1 <= 0) break;
                 rhs += t_rhs;
                 evf += t_evf;
