@@ -1411,6 +1411,38 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
         if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
     bad = blk_sum(bad, sh);
+    if (bad) {
+        // A list out of comp1 order is out of order LOCALLY: the double point of a kink (x + 1e-10) has overtaken the next
+        // grid point or two -- on fine grids (C5: 32 768 points, spacing below 1e-10 near a0) that happens in many periods,
+        // and the counting fallback below is quadratic (65 536 points: 1.5 s per cell, measured).  A few rounds of odd-even
+        // transposition WITHIN the lists put them in order first: neighbours of the same function are swapped only when
+        // strictly out of order, so fully tied points keep their input order (what the reference's stable qsort gives), and
+        // the final sorted stream is the same.  (The input arrays are the kernel's own work arrays.)
+        double *wm = (double *)im, *wc = (double *)ic, *wv = (double *)iv;
+        for (int round = 0; round < 64 && bad; round += 2) {
+            for (int par = 0; par < 2; par++) {
+                for (int i = 2 * (int)threadIdx.x + par; i + 1 < npts; i += 2 * ENV_BS) {
+                    if (ifn[i] != ifn[i + 1]) continue;
+                    const double am = wm[i], av = wv[i], bm = wm[i + 1], bv = wv[i + 1];
+                    if (bm < am || (bm == am && bv > av)) {  // strictly before in (M asc, V desc): swap the two points
+                        const double ac = wc[i];
+                        wm[i] = bm, wv[i] = bv, wc[i] = wc[i + 1];
+                        wm[i + 1] = am, wv[i + 1] = av, wc[i + 1] = ac;
+                    }
+                }
+                __syncthreads();
+            }
+            int b2 = 0;
+            for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
+                if (ifn[i] == ifn[i - 1] && !pt_before(wm[i - 1], wv[i - 1], ifn[i - 1], i - 1, wm[i], wv[i], ifn[i], i)) b2 = 1;
+            bad = blk_sum(b2, sh);
+        }
+        if (lds_keys) {  // (the staged M keys follow the lists)
+            __syncthreads();
+            for (int i = threadIdx.x; i < npts; i += ENV_BS) lkeys[i] = im[i];
+            __syncthreads();
+        }
+    }
     double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
     *fused = 0;
     if (!bad && cls) {
@@ -1452,14 +1484,20 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     // when every list was already ordered; after the counting fallback the lists are rebuilt from the sorted
     // stream (sequential, rare: a list is only out of order when a kink's double point overtakes a grid point).
     if (bad) {
-        if (threadIdx.x == 0) {
-            // `rank` is not needed as a permutation any more: overwrite it with the per-function position lists
-            for (int g = 0; g < nf; g++) {
-                if (dims[g] <= 0) continue;
-                int c = 0;
-                for (int r = 0; r < npts; r++)
-                    if (of[r] == g) rank[fstart[g] + c++] = r;
-            }
+        // `rank` is not needed as a permutation any more: overwrite it with the per-function position lists (every thread
+        // counts a function's points in its chunk of the sorted stream, a prefix over the threads places them)
+        const int C = (npts + ENV_BS - 1) / ENV_BS, qa = min(npts, (int)threadIdx.x * C), qb = min(npts, qa + C);
+        for (int g = 0; g < nf; g++) {
+            if (dims[g] <= 0) continue;
+            int c = 0;
+            for (int r = qa; r < qb; r++) c += (of[r] == g);
+            __syncthreads();
+            sh[threadIdx.x] = c;
+            __syncthreads();
+            int before = 0;
+            for (int t = 0; t < (int)threadIdx.x; t++) before += sh[t];
+            for (int r = qa; r < qb; r++)
+                if (of[r] == g) rank[fstart[g] + before++] = r;
         }
         __syncthreads();
     }
