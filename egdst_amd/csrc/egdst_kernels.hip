@@ -1299,6 +1299,46 @@ static __device__ __forceinline__ int blk_scan(int flag, int *sh, int *total)
     return off + ex;
 }
 
+// exclusive scan of one small count per thread; returns the exclusive prefix, *total the block total
+static __device__ __forceinline__ int blk_scan_int(int v, int *sh, int *total)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    int incl = v;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) sh[wave] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < ENV_NW; w++) {
+        if (w < wave) off += sh[w];
+        tot += sh[w];
+    }
+    *total = tot;
+    return off + incl - v;
+}
+// three reductions with one exchange: max of *a, bitwise or of *b, sum of *c
+static __device__ __forceinline__ void blk_reduce3(int *a, int *b, int *c, int *sh)
+{
+    int x = *a, y = *b, z = *c;
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        x = max(x, __shfl_xor(x, o));
+        y |= __shfl_xor(y, o);
+        z += __shfl_xor(z, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        const int w = threadIdx.x / WAVE;
+        sh[3 * w] = x, sh[3 * w + 1] = y, sh[3 * w + 2] = z;
+    }
+    __syncthreads();
+    x = sh[0], y = sh[1], z = sh[2];
+    for (int w = 1; w < ENV_NW; w++) x = max(x, sh[3 * w]), y |= sh[3 * w + 1], z += sh[3 * w + 2];
+    *a = x, *b = y, *c = z;
+}
+
 // strict order of comp1 (egdst_solver.c:1570-1582) extended by the original index (qsort of glibc is a
 // stable merge sort, so fully tied quadruples keep their input order)
 static __device__ __forceinline__ bool pt_before(double am, double av, int af, int ai, double bm, double bv, int bf, int bi)
@@ -1671,6 +1711,7 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
 #ifndef ENV_SEG_MINPTS
 #define ENV_SEG_MINPTS 192      // sorted points per segment below which cutting a walk is not worth it
 #endif
+#define ENV_CK 4         // candidates a thread compacts per chunk
 #define ENV_SMALLF 1024  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
                          // (C5 at full size: 292 pieces in one list; the reference allows 10000, :832)
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
@@ -1787,6 +1828,12 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     __shared__ double sg_lastg[ENV_MAXSEG];
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
     int nseg = 1, thstride = j.nthrhmax;
+#ifdef EGDST_STAMPS2
+    unsigned long long s2_ = wall_clock64();
+#define STAMP2(k) do { __syncthreads(); if (tid_ == 0 && j.dbg) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)j.dbg + (k), n_ - s2_); s2_ = n_; } } while (0)
+#else
+#define STAMP2(k)
+#endif
 #if !defined(EGDST_SEQ_WALK)
     {
         nseg = ENV_BS / WAVE;
@@ -1871,6 +1918,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         __syncthreads();
         nseg = sg_n;
     }
+    STAMP2(3);  // planning: cost scan, cuts
     if (nseg > 1) {
         double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
         if (wave_ < nseg) {  // (every thread owns a copy of the context: a wave points its own at its segment)
@@ -1894,7 +1942,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifdef EGDST_STAMPS
             if (lane_ == 0 && j.dbg) {  // diagnostic: longest segment (slot 0) and sum over segments (slot 1, was: classification)
                 const unsigned long long d_ = wall_clock64() - sgt0_;
+#ifndef EGDST_STAMPS2
                 atomicMax((unsigned long long *)j.dbg + 0, d_);
+#endif
                 atomicAdd((unsigned long long *)j.dbg + 1, d_);
             }
 #endif
@@ -1903,6 +1953,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
                 sg_lastg[sgi] = e.lastg;
             }
         }
+        STAMP2(4);  // the segments (wall: the longest one)
         __syncthreads();
         if (tid_ == 0) {  // do the predictions hold?
             int ok = 1, toi = 0, toj = 0;
@@ -1938,6 +1989,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
                 off += cnt;
                 offj += cntj;
             }
+            STAMP2(7);  // check + gather
             if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
             return;
         }
@@ -1952,6 +2004,14 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         *n = e.oi;
         *nth = e.oj;
     }
+#ifdef EGDST_STAMPS2
+    __syncthreads();
+    if (tid_ == 0 && j.dbg) {  // diagnostic: walks by one wave -- ticks, (<<40) how many, (<<52) how many of them not for being short
+        const int why = j.klog ? 1 : !j.wM ? 2 : j.nf > ENV_SEGNF ? 3 : j.npts < 2 * ENV_SEG_MINPTS ? 4 :
+                        (2 * (long long)j.npts + 128 + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap) ? 5 : 6;
+        atomicAdd((unsigned long long *)j.dbg + 0, (wall_clock64() - s2_) + (1ull << 40) + ((unsigned long long)(why != 4) << 52));
+    }
+#endif
 }
 
 // lcap: sorted points that fit the dynamic LDS (32 B each: sorted M/C/V, class word, 16-bit function id and position).
@@ -1968,7 +2028,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
 {
     EG_DYN_LDS(dynlds);
-    __shared__ int sh[ENV_MAXBS];
+    __shared__ int sh[ENV_MAXBS + 2];  // (+2: blk_reduce3 of a one-thread harness build)
     __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
     __shared__ int s_stack[2 * (ENV_SMALLF + 2)];
     __shared__ double s_evfa0[MS_ND];
@@ -2147,7 +2207,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
             if (!P.active) continue;
             any = 1;
             const size_t co = eg_cand(b, draw, ist, id);
-            int nreq = 0;
+            int nreq = 0, fusedstats = 0;
             evfa0 = P.evfa0;
             if (terminal) {
                 nreq = ngridm - 1;  // candidate indices 0..ngridm-1, all kept
@@ -2158,60 +2218,69 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
                 const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
                 // first requested point whose returned M stops the stream (:1100): the point itself is kept
                 int first = navail + 1;
-                for (int n = 1 + tid; n <= navail; n += ENV_BS)
-                    if (!(b.cR[co + n] < mmax)) {
-                        first = n;
-                        break;
-                    }
+                for (int n = 1 + tid; n <= navail; n += ENV_BS)  // (no early exit: the loads of a thread go out together)
+                    if (!(b.cR[co + n] < mmax)) first = min(first, n);
                 first = blk_min(first, sh);
                 nreq = min(first, navail);
-                int hard = 0, n1 = 0, n2 = 0, ev = 0;
-                for (int n = 1 + tid; n <= nreq; n += ENV_BS) {
-                    const int st = b.cSt[co + n];
-                    if (st < 0) hard = max(hard, -st);
-                    n1 += (st == 1);
-                    n2 += (st == 2);
-                    ev += b.cCnt[co + n];
-                }
-                hard = -blk_min(-hard, sh);
-                n1 = blk_sum(n1, sh);
-                n2 = blk_sum(n2, sh);
-                ev = blk_sum(ev, sh);
-                evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
-                if (hard) ENV_FAIL(hard);
-                if (n1) ENV_FAIL(26);  // k_fixup should have taken this stream over
-                if (n2) evfa0 = -INFINITY;
+                fusedstats = 1;
             }
             // ---- compaction of kept points into the choice's list ------------------------------
+            // Every thread takes ENV_CK consecutive candidates of a chunk of ENV_CK*ENV_BS, so a list of a few thousand is
+            // one chunk: one round of loads, one block scan.  The statistics of the requested points (hard errors, statuses
+            // 1 and 2, evaluation counts) ride along and are reduced once at the end.
+            int hard = 0, n12 = 0, ev = 0;
             {
                 int carry = 0;
-                for (int base = 0; base <= nreq; base += ENV_BS) {
-                    const int n = base + tid;
-                    int keepit = 0;
-                    if (n <= nreq) {
-                        if (terminal || P.seq)
-                            keepit = 1;
-                        else if (n == 0)
-                            keepit = P.np;
-                        else
-                            keepit = (b.cSt[co + n] == 0 && isfinite(b.cM[co + n]));
+                for (int base = 0; base <= nreq; base += ENV_CK * ENV_BS) {
+                    const int n0 = base + ENV_CK * tid;
+                    double vM[ENV_CK], vC[ENV_CK], vV[ENV_CK];
+                    int keep[ENV_CK], mine = 0;
+#pragma unroll
+                    for (int k = 0; k < ENV_CK; k++) {
+                        const int n = n0 + k;
+                        keep[k] = 0;
+                        vM[k] = vC[k] = vV[k] = 0;
+                        if (n <= nreq) {
+                            vM[k] = b.cM[co + n], vC[k] = b.cC[co + n], vV[k] = b.cV[co + n];
+                            if (terminal || P.seq)
+                                keep[k] = 1;
+                            else if (n == 0)
+                                keep[k] = P.np;
+                            else {
+                                const int st = b.cSt[co + n];
+                                if (st < 0) hard = max(hard, -st);
+                                n12 |= (st == 1) | ((st == 2) << 1);
+                                ev += b.cCnt[co + n];
+                                keep[k] = (st == 0 && isfinite(vM[k]));
+                            }
+                        }
+                        mine += keep[k];
                     }
                     int tot;
-                    const int ex = blk_scan(keepit, sh, &tot);
-                    if (keepit) {
-                        const int d = nall + carry + ex;
-                        if (d < 0 || (size_t)d >= W)
-                            s_oob = 1;
-                        else {
-                            pM[d] = b.cM[co + n];
-                            pC[d] = b.cC[co + n];
-                            pV[d] = b.cV[co + n];
-                            pF[d] = id;
+                    int d = nall + carry + blk_scan_int(mine, sh, &tot);
+#pragma unroll
+                    for (int k = 0; k < ENV_CK; k++)
+                        if (keep[k]) {
+                            if (d < 0 || (size_t)d >= W)
+                                s_oob = 1;
+                            else {
+                                pM[d] = vM[k];
+                                pC[d] = vC[k];
+                                pV[d] = vV[k];
+                                pF[d] = id;
+                            }
+                            d++;
                         }
-                    }
                     carry += tot;
                 }
                 cnt = carry;
+            }
+            if (fusedstats) {
+                blk_reduce3(&hard, &n12, &ev, sh);
+                evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
+                if (hard) ENV_FAIL(hard);
+                if (n12 & 1) ENV_FAIL(26);  // k_fixup should have taken this stream over
+                if (n12 & 2) evfa0 = -INFINITY;
             }
             __syncthreads();
             STAMP(0);  // stop rule + compaction
