@@ -1004,7 +1004,7 @@ template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L
     }
     e.pm = pm;
     e.lastg = lastg;
-#if defined(EGDST_STAMPS) && !defined(EGDST_STAMPS2)
+#if defined(EGDST_STAMPS) && !defined(EGDST_STAMPS2) && !defined(EGDST_STAMPS3)
     if (lane == 0 && e.dbg) {
         atomicAdd((unsigned long long *)e.dbg + 3, (w_nbatch << 32) | w_nstep);
         atomicAdd((unsigned long long *)e.dbg + 4, w_step);

@@ -1339,6 +1339,9 @@ static __device__ __forceinline__ void blk_reduce3(int *a, int *b, int *c, int *
     *a = x, *b = y, *c = z;
 }
 
+#ifdef EGDST_RANKCHK
+__device__ int g_rankchk;
+#endif
 // strict order of comp1 (egdst_solver.c:1570-1582) extended by the original index (qsort of glibc is a
 // stable merge sort, so fully tied quadruples keep their input order)
 static __device__ __forceinline__ bool pt_before(double am, double av, int af, int ai, double bm, double bv, int bf, int bi)
@@ -1352,81 +1355,112 @@ static __device__ __forceinline__ bool pt_before(double am, double av, int af, i
 // Rank of point i = (m, v, f) among npts points of nf functions whose lists are in comp1 order: the sum over the
 // functions of "how many of its points precede this one".  The same counts give the walk's class word of the point
 // (env_preclass): evaluated right here when cls_on.  KP: pointer type of the keys (LDS-staged or global).
-// pt_before for a key that lives in two arrays: the V key is read only when the M keys tie
-template <class KP, class KPV>
-static __device__ __forceinline__ bool eg_key_before(KP Km, KPV Kv, int k, int g, double m, double v, int f, int i)
+// A thread ranks ENV_RK CONSECUTIVE points (i0 .. i0+n-1).  Consecutive points of one list are neighbours in every other
+// list as well -- the count for point i+1 is at least the count for point i, and in merged lists of similar density a
+// position or two more -- so only a run's first point pays for a binary search over the whole of g; the others gallop on
+// from their predecessor's count.  (The count itself is unique: the lists are in comp1 order, checked by the caller.)
+// pt_before for a key that lives in two arrays (am: its M key, already read): the V key is read only when the M keys tie
+template <class KPV>
+static __device__ __forceinline__ bool eg_key_before_am(double am, KPV Kv, int k, int g, double m, double v, int f, int i)
 {
-    const double am = Km[k];
     if (am != m) return am < m;
     const double av = Kv[k];
     if (av != v) return av > v;
     if (g != f) return g < f;
     return k < i;
 }
-
+#ifndef ENV_RK
+#define ENV_RK 1  // (measured on C2, sort phase of one solve: 1: 1.94 ms, 2: 2.15 ms, 4: 2.65 ms -- see DESIGN.md)
+#endif
 template <class KP, class KPV, class ANA>
-static __device__ __forceinline__ int eg_rank_classify(int i, int nf, KP Km, KPV Kv, int f, double m, double v, const eg_ldsi *fstart,
-                                                       const eg_ldsi *dims, bool cls_on, double kbound, ANA ana, int *w_out)
+static __device__ __forceinline__ void eg_rank_classify_run(int i0, int n, int nf, KP Km, KPV Kv, const int *f, const double *m,
+                                                           const double *v, const eg_ldsi *fstart, const eg_ldsi *dims, bool cls_on,
+                                                           double kbound, ANA ana, int *r, int *w)
 {
-    int r = 0, w = 0;
-    bool force = false;
+    bool force[ENV_RK];
+#pragma unroll
+    for (int k = 0; k < ENV_RK; k++) r[k] = 0, w[k] = 0, force[k] = false;
     for (int g = 0; g < nf; g++) {
         const int dg = dims[g];
         if (dg <= 0) continue;
         const int s0 = fstart[g];
-        if (g == f) {
-            r += i - s0;
-            continue;
-        }
-        // lo = points of g that precede this one.  Most lists lie entirely on one side of the point (pieces of a
-        // folded choice list overlap only near the kinks), which two or three key reads settle
-        int lo = 0;
-        if (eg_key_before(Km, Kv, s0, g, m, v, f, i)) {
-            if (eg_key_before(Km, Kv, s0 + dg - 1, g, m, v, f, i))
-                lo = dg;
-            else if (dg >= 2 && eg_key_before(Km, Kv, s0 + dg - 2, g, m, v, f, i))
-                lo = dg - 1;  // (the last point of a closed piece is its extrapolation point at 1.5 mmax)
-            else {
-                int hi = dg >= 2 ? dg - 2 : dg - 1;
-                lo = 1;
-                while (lo < hi) {  // first position in [lo, hi] that does not precede the point
-                    const int mid = (lo + hi) >> 1;
-                    if (eg_key_before(Km, Kv, s0 + mid, g, m, v, f, i))
-                        lo = mid + 1;
-                    else
-                        hi = mid;
+        int prev = -1;  // count of the previous point when it belongs to the same list (and that list is not g)
+#pragma unroll
+        for (int k = 0; k < ENV_RK; k++) {
+            if (k >= n) continue;
+            const int i = i0 + k, fk = f[k];
+            const double mk = m[k], vk = v[k];
+            if (fk == g) {
+                r[k] += i - s0;
+                prev = -1;
+                continue;
+            }
+            int lo, hi;  // first position in [lo, hi] that does not precede the point (positions below lo do, hi does not or is dg)
+            if (prev >= 0 && k > 0 && f[k > 0 ? k - 1 : 0] == fk) {
+                lo = prev, hi = prev;
+                int step = 1;
+                for (;;) {
+                    if (hi >= dg) {
+                        hi = dg;
+                        break;
+                    }
+                    if (!eg_key_before_am(Km[s0 + hi], Kv, s0 + hi, g, mk, vk, fk, i)) break;
+                    lo = hi + 1;
+                    hi += step;
+                    step <<= 1;
+                }
+            } else {
+                // most lists lie entirely on one side of the point (pieces of a folded choice list overlap only near the
+                // kinks), which two or three key reads settle; the last point of a closed piece is its extrapolation point
+                lo = 0, hi = 0;
+                if (eg_key_before_am(Km[s0], Kv, s0, g, mk, vk, fk, i)) {
+                    const bool b1 = eg_key_before_am(Km[s0 + dg - 1], Kv, s0 + dg - 1, g, mk, vk, fk, i);
+                    const bool b2 = !b1 && dg >= 2 && eg_key_before_am(Km[s0 + dg - 2], Kv, s0 + dg - 2, g, mk, vk, fk, i);
+                    // (selects on purpose: an if / else-if / else chain here was miscompiled by hipcc 7.2 for gfx950 in an
+                    //  earlier form of this function -- the last branch set hi but not lo; -DEGDST_RANKCHK checks every rank)
+                    lo = b1 ? dg : (b2 ? dg - 1 : 1);
+                    hi = b1 ? dg : (b2 ? dg - 1 : (dg >= 2 ? dg - 2 : dg - 1));
                 }
             }
-        }
-        r += lo;
-        if (cls_on && !force) {
-            if (lo >= dg)
-                force = true;  // g has no point ahead: cannot happen below the bound
-            else {
-                double t;
-                if (lo >= 1) {  // env_fn_cnt on the keys: the segment between g's points lo-1 and lo
-                    const double ga = Km[s0 + lo - 1], gb = Km[s0 + lo], fa = Kv[s0 + lo - 1], fb = Kv[s0 + lo];
-                    if (m == ga)
-                        t = fa;
-                    else if (m < ga || m > gb)
-                        t = -INFINITY;
-                    else
-                        t = fb * (m - ga) / (gb - ga) + fa * (gb - m) / (gb - ga);
-                } else
-                    t = ana(g, m);
-                if (v < t) w |= 1;
-                if (t < v && nf <= 29) w |= (2 << g);
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (eg_key_before_am(Km[s0 + mid], Kv, s0 + mid, g, mk, vk, fk, i))
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            prev = lo;
+            r[k] += lo;
+            if (cls_on && !force[k]) {
+                if (lo >= dg)
+                    force[k] = true;  // g has no point ahead: cannot happen below the bound
+                else {
+                    double t;
+                    if (lo >= 1) {  // env_fn_cnt on the keys: the segment between g's points lo-1 and lo
+                        const double ga = Km[s0 + lo - 1], gb = Km[s0 + lo], fa = Kv[s0 + lo - 1], fb = Kv[s0 + lo];
+                        if (mk == ga)
+                            t = fa;
+                        else if (mk < ga || mk > gb)
+                            t = -INFINITY;
+                        else
+                            t = fb * (mk - ga) / (gb - ga) + fa * (gb - mk) / (gb - ga);
+                    } else
+                        t = ana(g, mk);
+                    if (vk < t) w[k] |= 1;
+                    if (t < vk && nf <= 29) w[k] |= (2 << g);
+                }
             }
         }
     }
     if (cls_on) {
-        if (force || !(m < kbound))
-            w = ENV_CLS_FORCE;
-        else if (nf > 29)
-            w |= ENV_CLS_NOMASK;
+#pragma unroll
+        for (int k = 0; k < ENV_RK; k++) {
+            if (force[k] || !(m[k] < kbound))
+                w[k] = ENV_CLS_FORCE;
+            else if (nf > 29)
+                w[k] |= ENV_CLS_NOMASK;
+        }
     }
-    *w_out = w;
-    return r;
 }
 
 // Sort npts points of nf functions (function f occupies [fstart[f], fstart[f]+dims[f]) of the input) into
@@ -1493,21 +1527,40 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
             }
         *fused = 1;
     }
-    for (int i = threadIdx.x; i < npts; i += ENV_BS) {
+    for (int i0 = ENV_RK * (int)threadIdx.x; i0 < npts && !bad; i0 += ENV_RK * ENV_BS) {  // a run of consecutive points per round
+        double m[ENV_RK], v[ENV_RK], c[ENV_RK];
+        int f[ENV_RK], r[ENV_RK], w[ENV_RK];
+        const int n = min(ENV_RK, npts - i0);
+#pragma unroll
+        for (int k = 0; k < ENV_RK; k++) {
+            m[k] = v[k] = c[k] = 0, f[k] = 0;
+            if (k < n) m[k] = im[i0 + k], v[k] = iv[i0 + k], c[k] = ic[i0 + k], f[k] = ifn[i0 + k];
+        }
+        if (lds_keys)
+            eg_rank_classify_run(i0, n, nf, (const eg_ldsd *)lkeys, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
+        else
+            eg_rank_classify_run(i0, n, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
+#pragma unroll
+        for (int k = 0; k < ENV_RK; k++) {
+            if (k >= n) continue;
+            if (r[k] < 0 || r[k] >= npts) {
+                *oob = 1;
+                continue;
+            }
+            if (cls) cls[r[k]] = w[k];
+            rank[i0 + k] = r[k];
+            om[r[k]] = m[k];
+            oc[r[k]] = c[k];
+            ov[r[k]] = v[k];
+            of[r[k]] = f[k];
+        }
+    }
+    for (int i = threadIdx.x; i < npts && bad; i += ENV_BS) {  // (lists still out of order after the presort: counting)
         const double m = im[i], v = iv[i];
         const int f = ifn[i];
         int r = 0;
-        if (!bad) {
-            int w = 0;
-            if (lds_keys)
-                r = eg_rank_classify(i, nf, (const eg_ldsd *)lkeys, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
-            else
-                r = eg_rank_classify(i, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
-            if (cls && r >= 0 && r < npts) cls[r] = w;
-        } else {
-            for (int j = 0; j < npts; j++)
-                if (pt_before(im[j], iv[j], ifn[j], j, m, v, f, i)) r++;
-        }
+        for (int j = 0; j < npts; j++)
+            if (pt_before(im[j], iv[j], ifn[j], j, m, v, f, i)) r++;
         if (r < 0 || r >= npts) {
             *oob = 1;
             continue;
@@ -1578,10 +1631,19 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
                                                         const double *iv, const int *ifn, const eg_ldsi *fstart,
                                                         const eg_ldsi *dims, eg_ldsd *R1, eg_ldsd *R2, eg_ldsd *R3,
                                                         eg_ldss *Lf, eg_ldss *Lp, int lcap, int *sh, int *oob,
-                                                        eg_ldsi *cls, int *fused, ANA ana)
+                                                        eg_ldsi *cls, int *fused, ANA ana, int *dbg = nullptr)
 {
     eg_ldsd *Km = R1, *Kv = R2, *Lm = R2, *Lv = R3, *Lc = R1;
     const int tid = threadIdx.x;
+#ifdef EGDST_EXP_NOCLS  // experiment: ranks only, the walk classifies
+    cls = nullptr;
+#endif
+#ifdef EGDST_STAMPS3  // diagnostic: staging + order check (slot 3), ranks (4), scatter (7)
+    unsigned long long t3_ = wall_clock64();
+#define ST3(k) do { __syncthreads(); if (tid == 0 && dbg) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)dbg + (k), n_ - t3_); t3_ = n_; } } while (0)
+#else
+#define ST3(k)
+#endif
     *fused = 0;
     for (int i = tid; i < npts; i += ENV_BS) {
         Km[i] = im[i];
@@ -1595,6 +1657,7 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
     int P = 1;
     while (P < npts) P <<= 1;
     if (bad && P > lcap) bad = 2;  // no room for the padded network: counting ranks instead
+    ST3(3);
     if (bad != 1) {
         double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
         if (!bad && cls) {
@@ -1605,18 +1668,46 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
                 }
             *fused = 1;
         }
-        for (int i = tid; i < npts; i += ENV_BS) {
+        for (int i0 = ENV_RK * tid; i0 < npts && !bad; i0 += ENV_RK * ENV_BS) {  // a run of ENV_RK consecutive points per round
+            double m[ENV_RK], v[ENV_RK];
+            int f[ENV_RK], r[ENV_RK], w[ENV_RK];  // (w: class words)
+            const int n = min(ENV_RK, npts - i0);
+#pragma unroll
+            for (int k = 0; k < ENV_RK; k++) {
+                m[k] = v[k] = 0, f[k] = 0;
+                if (k < n) m[k] = Km[i0 + k], v[k] = Kv[i0 + k], f[k] = ifn[i0 + k];
+            }
+            eg_rank_classify_run(i0, n, nf, Km, Kv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
+#ifdef EGDST_RANKCHK  // diagnostic build: every rank against a plain count
+            for (int k = 0; k < n; k++) {
+                const int i = i0 + k;
+                int rc_ = 0;
+                for (int j = 0; j < npts; j++)
+                    if (pt_before(Km[j], Kv[j], ifn[j], j, Km[i], Kv[i], ifn[i], i)) rc_++;
+                if (rc_ != r[k] && atomicAdd(&g_rankchk, 1) < 6)
+                    printf("rankchk i=%d k=%d n=%d r=%d count=%d f=%d npts=%d nf=%d tid=%d\n", i, k, n, r[k], rc_, f[k], npts, nf,
+                           (int)threadIdx.x);
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < ENV_RK; k++) {
+                if (k >= n) continue;
+                if (r[k] < 0 || r[k] >= npts) {
+                    *oob = 1;
+                    r[k] = -1;
+                } else {
+                    if (cls) cls[r[k]] = w[k];
+                    Lf[r[k]] = f[k];
+                }
+                Lp[i0 + k] = r[k];
+            }
+        }
+        for (int i = tid; i < npts && bad; i += ENV_BS) {
             const double m = Km[i], v = Kv[i];
             const int f = ifn[i];
             int r = 0;
-            if (!bad) {
-                int w = 0;  // class word of this point
-                r = eg_rank_classify(i, nf, Km, Kv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, &w);
-                if (cls && r >= 0 && r < npts) cls[r] = w;
-            } else {
-                for (int j = 0; j < npts; j++)
-                    if (pt_before(Km[j], Kv[j], ifn[j], j, m, v, f, i)) r++;
-            }
+            for (int j = 0; j < npts; j++)
+                if (pt_before(Km[j], Kv[j], ifn[j], j, m, v, f, i)) r++;
             if (r < 0 || r >= npts) {
                 *oob = 1;
                 r = -1;
@@ -1625,6 +1716,7 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
             Lp[i] = r;
         }
         __syncthreads();  // every rank is known
+        ST3(4);
         if (*oob) return Lp;
         for (int i = tid; i < npts; i += ENV_BS) Lv[Lp[i]] = Kv[i];  // R2 -> R3
         __syncthreads();
@@ -1632,6 +1724,7 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
         __syncthreads();
         for (int i = tid; i < npts; i += ENV_BS) Lc[Lp[i]] = ic[i];  // -> R1 (M keys are consumed)
         __syncthreads();
+        ST3(7);
         if (!bad) return Lp;
     } else {
         // bitonic network on (Km, Kv, Lf = function, Lp = input index); padding sorts last
@@ -1702,8 +1795,13 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
         }                                                                                 \
         return;                                                                           \
     } while (0)
-#define ENV_MAXSEG 8            // segments of a walk (one wave each)
-#define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per segment
+#ifndef ENV_MAXSEG
+#define ENV_MAXSEG 8            // segments of a walk; when there are more than walking waves, the waves take them from a queue
+                                // (measured on C2: 16 segments of >= 128 or 96 points do not shorten the longest one -- an event
+                                //  cluster cannot be cut -- and cost 0.2-0.3 ms per solve more to plan and gather)
+#endif
+#define ENV_MAXWW 8             // waves that walk segments
+#define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per walking wave
 #define ENV_SEGNF 126           // functions a segmented walk can handle (2*(nf+2) stack entries per slice)
 #ifndef ENV_SEG_EVENT_COST
 #define ENV_SEG_EVENT_COST 320  // what a crossing costs the walk, in regular positions (~5 batches of 64)
@@ -1824,7 +1922,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     // concatenation of the segments' outputs is exactly what the sequential walk writes (by induction from segment 0,
     // which starts from the true initial state) and is compacted in place; otherwise -- an exact tie at a cut, an error,
     // a full grid -- wave 0 simply does the whole walk again sequentially.  Same code per position either way.
-    __shared__ int sg_p[ENV_MAXSEG + 1], sg_oi[ENV_MAXSEG], sg_oj[ENV_MAXSEG], sg_err[ENV_MAXSEG], sg_pm[ENV_MAXSEG], sg_n;
+    __shared__ int sg_p[ENV_MAXSEG + 1], sg_oi[ENV_MAXSEG], sg_oj[ENV_MAXSEG], sg_err[ENV_MAXSEG], sg_pm[ENV_MAXSEG], sg_n, sg_next;
     __shared__ double sg_lastg[ENV_MAXSEG];
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
     int nseg = 1, thstride = j.nthrhmax;
@@ -1836,16 +1934,17 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #endif
 #if !defined(EGDST_SEQ_WALK)
     {
-        nseg = ENV_BS / WAVE;
-        if (nseg > ENV_MAXSEG) nseg = ENV_MAXSEG;
+        // more segments than waves: the walking waves (at most ENV_MAXWW: the slices of the cursor arrays) take them from
+        // a queue, which evens out what the cost estimate below gets wrong
+        nseg = (ENV_BS / WAVE >= 2) ? ENV_MAXSEG : 1;
         while (nseg > 1 && j.npts < ENV_SEG_MINPTS * nseg) nseg--;  // (a segment should be worth a few batches)
         // every segment writes its rows and thresholds into a region of its own in scratch arrays (rows: up to twice its
         // points plus 64; thresholds: the last 2*nthrhmax entries, thstride per segment)
         if (j.klog || !j.wM || j.nf > ENV_SEGNF || nseg < 2 ||
             2 * (long long)j.npts + 64 * nseg + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap)
             nseg = 1;
+        while (nseg > 1 && j.nthrhmax / nseg < 8) nseg--;
         thstride = j.nthrhmax / nseg;
-        if (thstride < 8) nseg = 1, thstride = j.nthrhmax;
         if (j.noseg) nseg = 1, thstride = j.nthrhmax;
     }
 #endif
@@ -1914,6 +2013,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             }
             sg_p[n] = j.npts;
             sg_n = n;
+            sg_next = min(ENV_BS / WAVE, ENV_MAXWW);  // (the first segments go to the waves in order)
         }
         __syncthreads();
         nseg = sg_n;
@@ -1921,17 +2021,19 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     STAMP2(3);  // planning: cost scan, cuts
     if (nseg > 1) {
         double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
-        if (wave_ < nseg) {  // (every thread owns a copy of the context: a wave points its own at its segment)
-            const int sgi = wave_, p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
+        // (every thread owns a copy of the context: a wave points its own at the segment it has taken)
+        for (int sgi = wave_; wave_ < ENV_MAXWW && sgi < nseg;) {
+            const int p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
             const size_t row0 = 2 * (size_t)p0 + 64 * (size_t)sgi;
-            e.cur = j.cur + sgi * ENV_SEGNF_SLICE;
-            e.mark = j.mark + sgi * ENV_SEGNF_SLICE;
-            e.stack = j.stack + sgi * 2 * ENV_SEGNF_SLICE;
+            e.cur = j.cur + wave_ * ENV_SEGNF_SLICE;
+            e.mark = j.mark + wave_ * ENV_SEGNF_SLICE;
+            e.stack = j.stack + wave_ * 2 * ENV_SEGNF_SLICE;
             e.stackcap = 2 * ENV_SEGNF_SLICE;
             e.og = j.wM + row0, e.ov = j.wV + row0, e.oc = j.wC + row0;
             e.ocap = 2 * (p1 - p0) + 64;
             e.oth = wTH + (size_t)sgi * thstride, e.oix = wIX + (size_t)sgi * thstride;
             e.nthrhmax = thstride;
+            e.err = 0;
             int pm0 = -1;
             double lastg0 = 0;
             if (sgi > 0) pm0 = (int)f[p0 - 1], lastg0 = m[p0 - 1];
@@ -1948,10 +2050,13 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
                 atomicAdd((unsigned long long *)j.dbg + 1, d_);
             }
 #endif
+            int nx = 0;
             if (lane_ == 0) {
                 sg_oi[sgi] = e.oi, sg_oj[sgi] = e.oj, sg_err[sgi] = e.err, sg_pm[sgi] = e.pm;
                 sg_lastg[sgi] = e.lastg;
+                nx = atomicAdd(&sg_next, 1);
             }
+            sgi = __shfl(nx, 0);
         }
         STAMP2(4);  // the segments (wall: the longest one)
         __syncthreads();
@@ -1972,22 +2077,23 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         }
         __syncthreads();
         if (sg_n) {
-            // gather: the segments' rows and thresholds, in order, to the front of the output
+            // gather: the segments' rows and thresholds, in order, to the front of the output (one pass over all of them:
+            // every thread finds the segment of its output row from the running totals)
             int off = 0, offj = 0;
-            for (int k = 0; k < nseg; k++) {
-                const size_t src = 2 * (size_t)sg_p[k] + 64 * (size_t)k;
-                const int cnt = sg_oi[k], cntj = sg_oj[k];
-                for (int r = tid_; r < cnt; r += ENV_BS) {
-                    j.og[off + r] = j.wM[src + r];
-                    j.ov[off + r] = j.wV[src + r];
-                    j.oc[off + r] = j.wC[src + r];
-                }
-                for (int r = tid_; r < cntj; r += ENV_BS) {
-                    j.oth[offj + r] = wTH[(size_t)k * thstride + r];
-                    j.oix[offj + r] = wIX[(size_t)k * thstride + r];
-                }
-                off += cnt;
-                offj += cntj;
+            for (int k = 0; k < nseg; k++) off += sg_oi[k], offj += sg_oj[k];
+            for (int r = tid_; r < off; r += ENV_BS) {
+                int k = 0, q = r;
+                while (q >= sg_oi[k]) q -= sg_oi[k], k++;
+                const size_t src = 2 * (size_t)sg_p[k] + 64 * (size_t)k + q;
+                j.og[r] = j.wM[src];
+                j.ov[r] = j.wV[src];
+                j.oc[r] = j.wC[src];
+            }
+            for (int r = tid_; r < offj; r += ENV_BS) {
+                int k = 0, q = r;
+                while (q >= sg_oj[k]) q -= sg_oj[k], k++;
+                j.oth[r] = wTH[(size_t)k * thstride + q];
+                j.oix[r] = wIX[(size_t)k * thstride + q];
             }
             STAMP2(7);  // check + gather
             if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
@@ -2420,7 +2526,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int i
         int fused = 0;
         if (job.npts <= lcap) {
             const eg_ldss *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
-                                               sh, &s_oob, Lq, &fused, ana);
+                                               sh, &s_oob, Lq, &fused, ana, job.dbg);
             STAMP(3);  // LDS sort
             if (s_oob) ENV_FAIL(2704);
             {

@@ -3,9 +3,10 @@ import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-for wl, tag in (('C2', '_stamps2'), ('C3', '_stamps2_c3')):
+extra = sys.argv[1:]
+for wl, tag in (('C2', '_stamps2'), ('C3', '_stamps2_c3'))[:1 if extra else 2]:
     m = workloads.WORKLOADS[wl]()[0]
-    lib = build.build_model(m, build_dir='egdst_amd/_models/' + tag, extra_flags=['-DEGDST_STAMPS', '-DEGDST_STAMPS2'])
+    lib = build.build_model(m, build_dir='egdst_amd/_models/' + tag + ''.join(extra).replace('-D', '_').replace('=', ''), extra_flags=['-DEGDST_STAMPS', '-DEGDST_STAMPS2'] + extra)
     s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=False)
     s.set_params(m.param_vector()[None]); s.solve()
     b0 = s.debug(0).view(np.uint64).copy()
@@ -15,5 +16,5 @@ for wl, tag in (('C2', '_stamps2'), ('C3', '_stamps2_c3')):
     print(wl, 'walks by one wave: %d (%d of them not short lists), %.2f ms' % (
         (one >> 40) & 4095, one >> 52, (one & ((1 << 40) - 1)) * 1e-5))
     d = raw.astype(np.float64) * 1e-5
-    print(wl, 'walk phase %.2f ms = plan %.2f + segments %.2f + check/gather %.2f | sum of segment times %.2f ms | sort %.2f stop+compact %.2f | walks %s' % (
+    print(extra, wl, 'walk phase %.2f ms = plan %.2f + segments %.2f + check/gather %.2f | sum of segment times %.2f ms | sort %.2f stop+compact %.2f | walks %s' % (
         d[6], d[3], d[4], d[7], d[1], d[5], d[2], s.walk_stats()[0].tolist()), flush=True)
