@@ -197,7 +197,11 @@ def main():
             dev[s, :padded] = torch.from_numpy(pp).cuda()
 
     stream = torch.cuda.Stream()
-    solver = runtime.Solver(lib, desc, ndraw=chunk, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap) if mine_n else None
+    # large batches of a workload may have a build variant of their own (workloads.BATCH_BUILD_FLAGS: k_envelope with fewer
+    # registers, so that the grid kernels run beside it); the one-draw latency legs below use the default build
+    batch_flags = workloads.BATCH_BUILD_FLAGS.get(args.workload, []) if (chunk >= workloads.BATCH_BUILD_MIN_DRAWS and not args.small) else []
+    lib_batch = build.build_model(model, extra_flags=batch_flags) if batch_flags else lib
+    solver = runtime.Solver(lib_batch, desc, ndraw=chunk, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap) if mine_n else None
     obj = torch.full((nsteps_all, max(padded, 1), 2), float('nan'), dtype=torch.float64, device='cuda')
     torch.cuda.synchronize()
 
@@ -281,7 +285,7 @@ def main():
                 args.workload, ' (REDUCED GRID, rehearsal only)' if args.small else '', model.label, desc['T'], desc['ngridm'],
                 desc['ny'], lib.info.nd, lib.info.nst, desc['a0'], desc['mmax']),
                 'draws_per_step_all_gpus': job, 'draws_per_gpu': args.ndraw if args.scaling == 'weak' else '%d..%d' % (job // world, -(-job // world)),
-                'chunk_draws_per_handle': chunk, 'chunks_per_step_rank0': nchunks, 'rows_cap': args.rows_cap,
+                'chunk_draws_per_handle': chunk, 'chunks_per_step_rank0': nchunks, 'rows_cap': args.rows_cap, 'batch_build_flags': batch_flags,
                 'draws_perturbed_every_step': not args.no_perturb,
                 'parallelism': 'draws sharded over %d rank(s), no data-path collective, one RCCL all-reduce of the objective' % world},
             'evals_executed_per_step': ev_exec_all / args.steps, 'evals_reference_per_step': ev_ref_all / args.steps,

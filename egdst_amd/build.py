@@ -42,6 +42,11 @@ def build_model(model, build_dir=None, force=False, extra_flags=()):
     from . import runtime
     text = codegen.generate_modelspec(model)
     tag = model_tag(model, text)
+    # build variants (extra -D flags from the caller -- workloads.BATCH_BUILD_FLAGS -- or, for experiments, from the
+    # environment) live in directories of their own
+    extra_flags = list(extra_flags) + os.environ.get('EGDST_HIPCC_EXTRA', '').split()
+    if extra_flags and not build_dir:
+        tag += '_' + ''.join(c if c.isalnum() else '_' for c in ''.join(extra_flags))
     d = build_dir or os.path.join(MODELS_DIR, tag)
     os.makedirs(d, exist_ok=True)
     spec = os.path.join(d, 'modelspec.h')

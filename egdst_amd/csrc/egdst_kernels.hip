@@ -2131,7 +2131,12 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 //       and their secondary envelopes as workgroups of their own, one per (cell, choice) -- they are independent of each
 //       other (egdst_solver.c:668: envelope2 per id) -- and then the primary envelope per cell.  The lists of part 1 live in
 //       per-choice slices of the cell's work arrays; what part 2 needs besides them is handed over in Batch.sec*.
-__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
+#ifdef ENV_VGPR  // experiment: fewer registers, so that waves of the grid kernels fit next to an envelope workgroup
+#define ENV_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(ENV_VGPR, ENV_VGPR)))
+#else
+#define ENV_VGPR_ATTR
+#endif
+__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
 {
     EG_DYN_LDS(dynlds);
     __shared__ int sh[ENV_MAXBS + 2];  // (+2: blk_reduce3 of a one-thread harness build)

@@ -60,3 +60,11 @@ def c5(ngridm=32768, T=100, ny=15):
 
 
 WORKLOADS = {'C1': c1, 'C2': c2, 'C3': c3, 'C4': c4, 'C5': c5}
+
+# Build variant for large batches.  k_envelope is compiled for 256 VGPRs by default, and a 512-thread workgroup of it then
+# owns the whole register file of its CU: no wave of the grid kernels runs beside it, although its waves wait ~75% of
+# their cycles (PMC).  -DENV_MINW=3 compiles it for 168 VGPRs (more spills), which leaves room for two grid-kernel waves
+# per SIMD.  Measured on MI355X: C2 x 4096 draws 243 -> 230 ms per batch, but one C2 solve 9.1 -> 9.6 ms,
+# one C3 solve 21.0 -> 23.4 ms, C3 x 64 42.5 -> 46.2 ms, C5 x 128 unchanged -- so it is a per-workload choice for batches.
+BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3']}
+BATCH_BUILD_MIN_DRAWS = 1024

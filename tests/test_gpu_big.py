@@ -96,3 +96,26 @@ def test_c5_batch_16_draws_full_size():
     assert np.array_equal(one.checksums(0), s.checksums(j)) and one.evals()[1][0] == s.evals()[1][j]
     one.close()
     s.close()
+
+
+def test_batch_build_variant_equals_the_fixture_and_the_default_build():
+    """bench.py solves large C2 batches with a build variant of its own (workloads.BATCH_BUILD_FLAGS: k_envelope compiled
+    for fewer registers).  Same source, same results: draw 0 against the glibc fixture, 48 perturbed draws against the
+    default build -- status, evaluation counts and the checksums of every cell."""
+    g = load('C2')
+    m, gen = workloads.c2()
+    flags = workloads.BATCH_BUILD_FLAGS['C2']
+    P = np.concatenate([m.param_vector()[None], gen(48)])
+    lib_v = build.build_model(m, extra_flags=flags)
+    assert lib_v.path != build.build_model(m).path
+    sv = runtime.Solver(lib_v, m.descriptor(), ndraw=len(P), keep_history=True)
+    sv.set_params(P)
+    sv.solve(raise_on_error=False)
+    check_draw(sv, 0, g)
+    sd = solve_batch(m, P)
+    assert np.array_equal(sv.status()[0], sd.status()[0])
+    assert np.array_equal(sv.evals()[1], sd.evals()[1])
+    for d in range(len(P)):
+        assert np.array_equal(sv.checksums(d), sd.checksums(d)), d
+    sv.close()
+    sd.close()
