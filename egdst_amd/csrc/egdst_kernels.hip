@@ -790,7 +790,10 @@ __global__ void __launch_bounds__(WAVE) k_fixup_scan(Batch b, int it, int *cnt, 
     if (resend && lane == 0) list[atomicAdd((unsigned *)cnt, 1u)] = combo;
 }
 
-__global__ void __launch_bounds__(FIX_BS) k_fixup(Batch b, int it, const int *cnt, const int *list)
+#ifndef FIX_MINW
+#define FIX_MINW 1  // (3: at most 168 VGPRs, so that a k_fixup wave fits a SIMD beside two waves of the -DENV_MINW=3 k_envelope)
+#endif
+__global__ void __launch_bounds__(FIX_BS, FIX_MINW) k_fixup(Batch b, int it, const int *cnt, const int *list)
 {
     const int n = *cnt;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {

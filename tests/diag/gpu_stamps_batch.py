@@ -6,7 +6,10 @@ sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
 m, gen = workloads.c2()
-lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps', extra_flags=['-DEGDST_STAMPS'])
+import os
+variant = os.environ.get('EGDST_HIPCC_EXTRA', '')
+lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps' + ''.join(c for c in variant if c.isalnum()), extra_flags=['-DEGDST_STAMPS'])
+print('build variant:', variant or '(default)')
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 P = gen(nd)
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
