@@ -42,6 +42,7 @@ struct Batch {
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
     unsigned *work;      // [ndraw] re-basing calls of the draw's guess streams in this solve (straggler detection)
+    unsigned *nregen;    // [ndraw] guess streams of the draw that k_fixup regenerated in this solve (schedule: such draws share groups)
     const double *par;   // [ndraw][MS_NPARAM]
     const double *qw;    // [ny] weights
     const double *qz;    // [ny] standard-normal nodes (Acklam of the GL abscissae, egdst_solver.c:164)

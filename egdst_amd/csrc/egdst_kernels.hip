@@ -38,7 +38,9 @@
 #ifndef EG_FIX_LROWS
 #define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
 #endif
+#ifndef EG_SEQ_AFTER_RESEND
 #define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
+#endif
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
 #endif
@@ -406,6 +408,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     int last_cnt = 0;  // evaluations of the most recent expectation
     int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
+#ifdef EGDST_FIXSTAT  // diagnostic: what a regeneration consists of (dbg ints 8..11, ticks in ints 12-13)
+    int fs_batches = 0, fs_single = 0, fs_resend = 0;
+    const unsigned long long fs_t0 = wall_clock64();
+#endif
     for (;;) {
         // ---- next guess -------------------------------------------------------------------
         if (ncalls + 1 >= b.g.ngridmax) {  // runaway guard (:963-978): the stream simply ends
@@ -530,6 +536,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 __shared__ unsigned long long sx_can[NW], sx_hard[NW], sx_neg[NW], sx_stop[NW], sx_kept[NW], sx_inf[NW];
                 __shared__ int sx_hst[NW], sx_cnt[NW], sx_bist;
                 __shared__ double sx_take[2], sx_neg4[3];
+#ifdef EGDST_FIXSTAT
+                fs_batches++;
+#endif
                 const int gl = wave * WAVE + lane;  // position of this thread's guess in the batch
                 const int n = ngenerated + gl;      // value of `ngenerated` at this thread's call
                 const bool can = n < ntogenerate && (ncalls + 1 + gl) < b.g.ngridmax;
@@ -631,6 +640,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 }
                 keep = 1;
                 if (negnext) {  // the next call hit c1<=0 (:583-621): prepare the resend
+#ifdef EGDST_FIXSTAT
+                    fs_resend++;
+#endif
                     seq_left = EG_SEQ_AFTER_RESEND;
                     ms_pv nb;
                     nb.it = it + 1;
@@ -657,6 +669,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
                 break;  // stream ends (:1150-1152)
         }
         // ---- evaluate the guess -----------------------------------------------------------
+#ifdef EGDST_FIXSTAT
+        fs_single++;
+#endif
         double rhs, evf;
         int bist = 0;
         double bshock = 0, bcash = 0;
@@ -725,6 +740,13 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
 #ifdef EGDST_EMU
     if (lead && full && getenv("EGDST_TRACE_FIXUP"))
         fprintf(stderr, "fixup end it=%d id=%d ncalls=%d ngen=%d np=%d last=%g M=%g nev=%d\n", it, id, ncalls, ngenerated, np, last, M, nev);
+#endif
+#ifdef EGDST_FIXSTAT
+    if (lead && full) {
+        atomicAdd(&b.dbg[16 * draw + 8], fs_batches), atomicAdd(&b.dbg[16 * draw + 9], fs_single);
+        atomicAdd(&b.dbg[16 * draw + 10], fs_resend), atomicAdd(&b.dbg[16 * draw + 11], 1);
+        atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 6, wall_clock64() - fs_t0);
+    }
 #endif
     // re-basing calls of this stream beyond the regular ones: the host schedules draws with many of them apart
     if (lead && ncalls - skipped > (full ? ntogenerate : 0) + 64)
@@ -802,6 +824,7 @@ __global__ void __launch_bounds__(FIX_BS, FIX_MINW) k_fixup(Batch b, int it, con
 #ifdef EGDST_EMU
         if (threadIdx.x == 0 && getenv("EGDST_TRACE_FIXUP")) fprintf(stderr, "fixup it=%d draw=%d ist=%d id=%d\n", it, draw, ist, id);
 #endif
+        if (threadIdx.x == 0) atomicAdd(&b.nregen[draw], 1u);
         eg_adraw_cycle<FIX_BS / WAVE, 1>(b, it, draw, ist, id);
         __syncthreads();  // the LDS buffers of the stream generator are reused by the next listed stream
     }
@@ -2047,7 +2070,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifdef EGDST_STAMPS
             if (lane_ == 0 && j.dbg) {  // diagnostic: longest segment (slot 0) and sum over segments (slot 1, was: classification)
                 const unsigned long long d_ = wall_clock64() - sgt0_;
-#ifndef EGDST_STAMPS2
+#if !defined(EGDST_STAMPS2) && !defined(EGDST_STAMPS5)
                 atomicMax((unsigned long long *)j.dbg + 0, d_);
 #endif
                 atomicAdd((unsigned long long *)j.dbg + 1, d_);
@@ -2142,6 +2165,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
 {
     EG_DYN_LDS(dynlds);
+#ifdef EGDST_STAMPS5  // diagnostic: residency of the whole workgroup (slot 0), completed cells only
+    const unsigned long long wg_t0_ = wall_clock64();
+#endif
     __shared__ int sh[ENV_MAXBS + 2];  // (+2: blk_reduce3 of a one-thread harness build)
     __shared__ int s_fstart[ENV_SMALLF], s_fdims[ENV_SMALLF], s_fcur[ENV_SMALLF], s_fmark[ENV_SMALLF];
     __shared__ int s_stack[2 * (ENV_SMALLF + 2)];
@@ -2617,6 +2643,9 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(
                     oM[1], oC[1], oV[1], oM[outn], oV[outn]);
 #endif
         if (evals) atomicAdd(&b.evals[draw], evals);
+#ifdef EGDST_STAMPS5
+        atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 0, wall_clock64() - wg_t0_);
+#endif
         {   // algorithmic bytes of this cell: its rows written once (M, C, V; A = M - C is derived on export) and,
             // for the EGM periods, the next-period table of the same state index read once
             unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull * (unsigned long long)outm;

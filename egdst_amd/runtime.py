@@ -31,7 +31,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_status', 'egdst_get_evals', 'egdst_cell_dims', 'egdst_get_cell_M', 'egdst_get_cell_D',
                'egdst_get_solution', 'egdst_simulate', 'egdst_device_tables', 'egdst_get_debug', 'egdst_set_profile',
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
-               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_call', 'egdst_simulate_moments',
+               'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_get_regenerations', 'egdst_call', 'egdst_simulate_moments',
                'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited', 'egdst_simulate_batch_moments',
                'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout', 'egdst_get_walk_stats']
 
@@ -221,6 +221,12 @@ class Solver:
         """re-basing calls per draw in the last solve (egdst_get_work)"""
         out = np.zeros(self.ndraw, dtype=np.uint32)
         self.lib.check(self.lib.lib.egdst_get_work(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def regenerations(self):
+        """regenerated guess streams per draw in the last solve (egdst_get_regenerations)"""
+        out = np.zeros(self.ndraw, dtype=np.uint32)
+        self.lib.check(self.lib.lib.egdst_get_regenerations(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def geometry(self):

@@ -110,6 +110,9 @@ int egdst_set_adaptive(egdst_handle *h, int on);
 int egdst_get_schedule(egdst_handle *h, int *groups, int *lanes, int *stragglers);
 /* Re-basing calls of every draw's guess streams in the last solve (the straggler measure). */
 int egdst_get_work(egdst_handle *h, unsigned *out /* [ndraw] */);
+/* Guess streams of every draw that had to be regenerated sequentially in the last solve (zero-consumption signal inside
+ * the grid stage, egdst_solver.c:1080-1099): a diagnostic of where a batch spends sequential time. */
+int egdst_get_regenerations(egdst_handle *h, unsigned *out /* [ndraw] */);
 /* Physical geometry of the handle: rows per list and row stride of the device tables (egdst_device_tables). */
 int egdst_geometry(egdst_handle *h, int *rows_cap, int *table_stride);
 

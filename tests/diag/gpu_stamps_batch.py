@@ -8,7 +8,7 @@ from egdst_amd import build, runtime, workloads
 m, gen = workloads.c2()
 import os
 variant = os.environ.get('EGDST_HIPCC_EXTRA', '')
-lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps' + ''.join(c for c in variant if c.isalnum()), extra_flags=['-DEGDST_STAMPS'])
+lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps' + ''.join(c for c in variant if c.isalnum()), extra_flags=['-DEGDST_STAMPS', '-DEGDST_STAMPS5'])
 print('build variant:', variant or '(default)')
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 P = gen(nd)
@@ -19,8 +19,8 @@ tot = np.zeros(8)
 for d in range(nd):
     tot += s.debug(d).view(np.uint64).astype(np.float64)
 tot *= 1e-2 / 2   # ticks of 10 ns -> us, two solves accumulated
-print('batch of %d: solve %.1f ms | per solve, summed over workgroups: stop+compact %.0f ms, sort %.0f ms, walk %.0f ms -> total/256 CUs = %.0f ms' % (
-    nd, dt * 1e3, tot[2] * 1e-3, tot[5] * 1e-3, tot[6] * 1e-3, (tot[2] + tot[5] + tot[6]) * 1e-3 / 256))
+print('batch of %d: solve %.1f ms | per solve, summed over workgroups: stop+compact %.0f ms, sort %.0f ms, walk %.0f ms -> total/256 CUs = %.0f ms; whole workgroups (entry to exit) / 256 CUs = %.0f ms' % (
+    nd, dt * 1e3, tot[2] * 1e-3, tot[5] * 1e-3, tot[6] * 1e-3, (tot[2] + tot[5] + tot[6]) * 1e-3 / 256, tot[0] * 1e-3 / 256))
 s.close()
 s1 = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=False)
 acc = np.zeros(8); n1 = min(nd, 64)
