@@ -59,11 +59,15 @@ def build_model(model, build_dir=None, force=False, extra_flags=()):
                  os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst_math.h')),
                  os.path.getmtime(os.path.join(HERE, '..', 'include', 'egdst_math_tables.h')))
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+        tmp = '%s.tmp.%d' % (lib, os.getpid())  # (several ranks may find the library stale at once: build aside, rename)
         cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ['-I', d, '-I', CSRC, '-I', os.path.join(HERE, '..', 'include'),
-                                                              os.path.join(CSRC, 'egdst_kernels.hip'), '-o', lib]
+                                                              os.path.join(CSRC, 'egdst_kernels.hip'), '-o', tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise BuildError('hipcc failed for model %r:\n%s\n%s' % (model.label, ' '.join(cmd), r.stderr[-6000:]))
+        os.replace(tmp, lib)
     model.make_simlabels()
     model.dir = d
     return runtime.ModelLibrary(lib, tag)
