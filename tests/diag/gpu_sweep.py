@@ -1,5 +1,5 @@
 """Validation sweep: many C2 draws on the GPU against the oracle -- status and evaluation counts for all of them, complete
-tables (bit for bit) for a subset.    python tests/diag/gpu_sweep.py <ndraw> <ntables>"""
+tables (bit for bit) for a subset.    python tests/diag/gpu_sweep.py <ndraw> <ntables> [batch]   (batch: the build variant bench.py uses for large batches)"""
 import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')  # run from the repo root
 import numpy as np
@@ -8,7 +8,8 @@ from oracle_harness import Oracle
 from parity import compare
 nd, nt = int(sys.argv[1]), int(sys.argv[2])
 m, gen = workloads.c2()
-lib = build.build_model(m)
+lib = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS['C2'] if len(sys.argv) > 3 and sys.argv[3] == 'batch' else ())
+print('library:', lib.path)
 P = gen(nd)
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
 s.set_params(P); s.solve(raise_on_error=False); s.solve(raise_on_error=False)   # second solve: adaptive schedule
