@@ -1836,7 +1836,10 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
 #define ENV_SEG_MINPTS 192      // sorted points per segment below which cutting a walk is not worth it
 #endif
 #define ENV_CK 4         // candidates a thread compacts per chunk
-#define ENV_SMALLF 1024  // functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
+#ifndef ENV_SMALLF
+#define ENV_SMALLF 1024
+#endif
+// ENV_SMALLF: functions (choices, or monotone pieces of one choice) whose bookkeeping fits the LDS arrays
                          // (C5 at full size: 292 pieces in one list; the reference allows 10000, :832)
 static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookkeeping arrays");
 
