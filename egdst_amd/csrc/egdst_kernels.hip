@@ -896,7 +896,10 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
     const int n1 = t.len;
     const int i = eg_bracket(x, M, n1, 0);
     const double mlast = M[n1 - 1], mfirst = M[1];
-    double c1 = eg_lerp(x, M[i], M[i + 1], t.C[i], t.C[i + 1]);
+    // rows i and i+1 of C and of V in ONE round of global reads: away from the table's ends valuefunc's bracket is the same
+    // pair of rows (j+1 == i below), and a lane that waits twice per evaluation waits half as often
+    const double Ci = t.C[i], Ci1 = t.C[i + 1], Vi = t.V[i], Vi1 = t.V[i + 1];
+    double c1 = eg_lerp(x, M[i], M[i + 1], Ci, Ci1);
     if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
     *t_rhs = 0;
     *t_evf = 0;
@@ -912,7 +915,7 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
         val = ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
     else {
         const int j = eg_second_bracket(x, i, M[2], M[n1 - 2], n1);  // == eg_bracket(x, M + 1, n1 - 1, 0)
-        const double f0 = t.V[j + 1], f1 = t.V[j + 2];
+        const double f0 = (j + 1 == i) ? Vi : t.V[j + 1], f1 = (j + 1 == i) ? Vi1 : t.V[j + 2];
         if (!isfinite(f0))
             val = f0;
         else if (!isfinite(f1))
@@ -967,7 +970,9 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
     const int n1 = t.len;
     const int i = eg_bracket_sampled(x, S, ns, stride, t.M, n1, edge);
     const double mlast = edge[3], mfirst = edge[0];
-    double c1 = eg_lerp(x, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
+    // (rows i and i+1 of M, C and V in one round of global reads, see eg_term_lds)
+    const double Mi = t.M[i], Mi1 = t.M[i + 1], Ci = t.C[i], Ci1 = t.C[i + 1], Vi = t.V[i], Vi1 = t.V[i + 1];
+    double c1 = eg_lerp(x, Mi, Mi1, Ci, Ci1);
     if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
     *t_rhs = 0;
     *t_evf = 0;
@@ -983,13 +988,14 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
         val = ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
     else {
         const int j = eg_second_bracket(x, i, edge[1], edge[2], n1);  // == eg_bracket(x, M + 1, n1 - 1, 0)
-        const double f0 = t.V[j + 1], f1 = t.V[j + 2];
+        const bool same = (j + 1 == i);
+        const double f0 = same ? Vi : t.V[j + 1], f1 = same ? Vi1 : t.V[j + 2];
         if (!isfinite(f0))
             val = f0;
         else if (!isfinite(f1))
             val = f1;
         else {
-            const double g0 = t.M[j + 1], g1 = t.M[j + 2];
+            const double g0 = same ? Mi : t.M[j + 1], g1 = same ? Mi1 : t.M[j + 2];
             if (x > a0 && (x > mlast || x < mfirst)) {
                 const double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
                 val = f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
