@@ -197,9 +197,9 @@ def main():
             dev[s, :padded] = torch.from_numpy(pp).cuda()
 
     stream = torch.cuda.Stream()
-    # large batches of a workload may have a build variant of their own (workloads.BATCH_BUILD_FLAGS: k_envelope with fewer
-    # registers, so that the grid kernels run beside it); the one-draw latency legs below use the default build
-    batch_flags = workloads.BATCH_BUILD_FLAGS.get(args.workload, []) if (chunk >= workloads.BATCH_BUILD_MIN_DRAWS and not args.small) else []
+    # large batches of a workload may have a build variant of their own (workloads.BATCH_BUILD_FLAGS: other register
+    # budgets for k_envelope or k_grid_lds); the one-draw latency legs below use the default build
+    batch_flags = workloads.BATCH_BUILD_FLAGS.get(args.workload, []) if (chunk >= workloads.BATCH_BUILD_MIN_DRAWS.get(args.workload, 1 << 30) and not args.small) else []
     lib_batch = build.build_model(model, extra_flags=batch_flags) if batch_flags else lib
     solver = runtime.Solver(lib_batch, desc, ndraw=chunk, keep_history=False, stream=stream.cuda_stream, rows_cap=args.rows_cap) if mine_n else None
     obj = torch.full((nsteps_all, max(padded, 1), 2), float('nan'), dtype=torch.float64, device='cuda')

@@ -25,7 +25,9 @@
 
 #ifndef WAVE  // the sanitizer harness (tests/cpu_emu) overrides these
 #define WAVE 64
+#ifndef GRID_BS
 #define GRID_BS 256
+#endif
 #define ENV_MAXBS 512  // most threads of a k_envelope workgroup (what it is compiled for: <= 256 VGPRs)
 #else
 #define ENV_MAXBS ENV_BS_EMU
@@ -1025,7 +1027,10 @@ __global__ void __launch_bounds__(GRID_BS) k_sortcheck(Batch b, int it)
     if (threadIdx.x == 0) b.tsorted[(size_t)draw * MS_NST + ist] = (t.len >= 4 && t.len <= b.g.Sp && !bad_) ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(GRID_BS) k_grid_lds(Batch b, int it, int lrows)
+#ifndef GRID_MINW
+#define GRID_MINW 1  // (experiments: waves per SIMD k_grid_lds is compiled for; 8 = at most 64 VGPRs)
+#endif
+__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(Batch b, int it, int lrows)
 {
     EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
     __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded

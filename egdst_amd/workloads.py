@@ -61,10 +61,17 @@ def c5(ngridm=32768, T=100, ny=15):
 
 WORKLOADS = {'C1': c1, 'C2': c2, 'C3': c3, 'C4': c4, 'C5': c5}
 
-# Build variant for large batches.  k_envelope is compiled for 256 VGPRs by default, and a 512-thread workgroup of it then
-# owns the whole register file of its CU: no wave of the grid kernels runs beside it, although its waves wait ~75% of
-# their cycles (PMC).  -DENV_MINW=3 compiles it for 168 VGPRs (more spills), which leaves room for two grid-kernel waves
-# per SIMD.  Measured on MI355X: C2 x 4096 draws 243 -> 230 ms per batch, but one C2 solve 9.1 -> 9.6 ms,
-# one C3 solve 21.0 -> 23.4 ms, C3 x 64 42.5 -> 46.2 ms, C5 x 128 unchanged -- so it is a per-workload choice for batches.
-BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3']}
-BATCH_BUILD_MIN_DRAWS = 1024
+# Build variants for large batches (same source, other register budgets; `bench.py` uses them for handles of at least
+# BATCH_BUILD_MIN_DRAWS[workload] draws, the one-draw latency legs use the default build; tests/test_gpu_big.py holds them to
+# the full-size fixtures).  Measured on MI355X:
+#  * -DENV_MINW=3: k_envelope is compiled for 256 VGPRs by default, and a 512-thread workgroup of it then owns the whole
+#    register file of its CU: no wave of the grid kernels runs beside it, although its waves wait ~75% of their cycles (PMC).
+#    168 VGPRs (more spills) leave room for two grid-kernel waves per SIMD: C2 x 4096 draws 243 -> 230 ms per batch, but one
+#    C2 solve 9.1 -> 9.6 ms, one C3 solve 21.0 -> 23.4 ms, C3 x 64 42.5 -> 46.2 ms, C5 x 128 unchanged.
+#  * -DGRID_MINW=8: k_grid_lds for 64 VGPRs (44-84 B of spills) instead of 77-92, eight waves per SIMD instead of five or
+#    six, for the long tables of C4 and C5 whose bracket searches finish in global memory: C4 x 32 draws 63.6 -> 58.8 ms,
+#    C5 x 128 draws 4.32 -> 3.76 s; C2 unchanged, C3 x 64 (pow-heavy) 42.5 -> 48.0 ms.
+#  * -DGRID_BS=1024: workgroups of 1024 grid points share one staged index (C4 x 32: 58.8 -> 54.3 ms; 512: 55.5; C5 x 128 with
+#    512: 3.84 s against 3.78, not used there).
+BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3'], 'C4': ['-DGRID_MINW=8', '-DGRID_BS=1024'], 'C5': ['-DGRID_MINW=8']}
+BATCH_BUILD_MIN_DRAWS = {'C2': 1024, 'C4': 16, 'C5': 64}

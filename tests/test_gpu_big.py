@@ -119,3 +119,27 @@ def test_batch_build_variant_equals_the_fixture_and_the_default_build():
         assert np.array_equal(sv.checksums(d), sd.checksums(d)), d
     sv.close()
     sd.close()
+
+
+@pytest.mark.parametrize('name,wl', [('C4', 'C4'), ('C5_T60_n2000', 'C5')])
+def test_batch_build_variants_of_the_stress_configs_equal_the_fixtures(name, wl):
+    """C4 and C5 batches are solved with k_grid_lds compiled for eight waves per SIMD (workloads.BATCH_BUILD_FLAGS): the
+    variant against the glibc fixture of the configuration, and against the default build on a few draws."""
+    g = load(name)
+    m, par = BIG[name][0]()
+    flags = workloads.BATCH_BUILD_FLAGS[wl]
+    lib_v = build.build_model(m, extra_flags=flags)
+    assert lib_v.path != build.build_model(m).path
+    P = np.atleast_2d(np.asarray(m.param_vector() if par is None else par, dtype=np.float64))
+    gen = workloads.WORKLOADS[wl]()[1]
+    P = np.concatenate([P[:1], gen(3)])
+    sv = runtime.Solver(lib_v, m.descriptor(), ndraw=len(P), keep_history=True)
+    sv.set_params(P)
+    sv.solve(raise_on_error=False)
+    check_draw(sv, 0, g)
+    sd = solve_batch(m, P)
+    assert np.array_equal(sv.status()[0], sd.status()[0]) and np.array_equal(sv.evals()[1], sd.evals()[1])
+    for d in range(len(P)):
+        assert np.array_equal(sv.checksums(d), sd.checksums(d)), d
+    sv.close()
+    sd.close()
