@@ -1412,8 +1412,12 @@ static __device__ __forceinline__ bool eg_key_before_am(double am, KPV Kv, int k
 template <class KP, class KPV, class ANA>
 static __device__ __forceinline__ void eg_rank_classify_run(int i0, int n, int nf, KP Km, KPV Kv, const int *f, const double *m,
                                                            const double *v, const eg_ldsi *fstart, const eg_ldsi *dims, bool cls_on,
-                                                           double kbound, ANA ana, int *r, int *w)
+                                                           double kbound, ANA ana, int *r, int *w, const eg_ldsd *S = nullptr,
+                                                           int sk = 0)
 {
+    // S, sk: a sampled index of the keys in LDS (S[j] = Km[j * sk]) for streams whose keys do not fit (C5 at full size:
+    // 65 536 points and more): the search runs on the sample first and is finished in the window between two samples, two
+    // or three dependent global reads instead of seventeen
     bool force[ENV_RK];
 #pragma unroll
     for (int k = 0; k < ENV_RK; k++) r[k] = 0, w[k] = 0, force[k] = false;
@@ -1458,6 +1462,21 @@ static __device__ __forceinline__ void eg_rank_classify_run(int i0, int n, int n
                     lo = b1 ? dg : (b2 ? dg - 1 : 1);
                     hi = b1 ? dg : (b2 ? dg - 1 : (dg >= 2 ? dg - 2 : dg - 1));
                 }
+            }
+            if (sk > 1 && hi - lo > sk) {
+                // positions below a = s0+lo precede the point, position z = s0+hi does not (or is the end of g); the sampled
+                // positions in [a, z) are ja*sk .. jz*sk: the first of them that does not precede the point bounds the window
+                const int a = s0 + lo, z = s0 + hi, ja = (a + sk - 1) / sk, jz = (z - 1) / sk;
+                int l = ja, h = jz + 1;
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (eg_key_before_am(S[mid], Kv, mid * sk, g, mk, vk, fk, i))
+                        l = mid + 1;
+                    else
+                        h = mid;
+                }
+                if (l > ja) lo = (l - 1) * sk + 1 - s0;
+                if (l <= jz) hi = l * sk - s0;
             }
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -1514,8 +1533,13 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     // the binary searches of the rank merge then run on LDS, and the V keys are read from global memory only at M ties
     // and at the bracket of the classification.
     const bool lds_keys = lkeys != nullptr && npts <= lkeys_cap;
+    // (longer still: every sk-th key, a sampled index -- see eg_rank_classify_run)
+    const int sk = (lkeys != nullptr && !lds_keys && lkeys_cap >= 64) ? (npts + lkeys_cap - 1) / lkeys_cap : 0;
     if (lds_keys) {
         for (int i = threadIdx.x; i < npts; i += ENV_BS) lkeys[i] = im[i];
+        __syncthreads();
+    } else if (sk > 1) {
+        for (int j = threadIdx.x; j * sk < npts; j += ENV_BS) lkeys[j] = im[(size_t)j * sk];
         __syncthreads();
     }
     int bad = 0;
@@ -1552,6 +1576,10 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
             __syncthreads();
             for (int i = threadIdx.x; i < npts; i += ENV_BS) lkeys[i] = im[i];
             __syncthreads();
+        } else if (sk > 1) {
+            __syncthreads();
+            for (int j = threadIdx.x; j * sk < npts; j += ENV_BS) lkeys[j] = im[(size_t)j * sk];
+            __syncthreads();
         }
     }
     double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
@@ -1576,7 +1604,8 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         if (lds_keys)
             eg_rank_classify_run(i0, n, nf, (const eg_ldsd *)lkeys, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
         else
-            eg_rank_classify_run(i0, n, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
+            eg_rank_classify_run(i0, n, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w,
+                                 (const eg_ldsd *)lkeys, sk);
 #pragma unroll
         for (int k = 0; k < ENV_RK; k++) {
             if (k >= n) continue;
@@ -1838,8 +1867,12 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
                                 //  cluster cannot be cut -- and cost 0.2-0.3 ms per solve more to plan and gather)
 #endif
 #define ENV_MAXWW 8             // waves that walk segments
-#define ENV_SEGNF_SLICE 128     // the per-function LDS arrays (cur, mark, stack) are cut into one slice per walking wave
-#define ENV_SEGNF 126           // functions a segmented walk can handle (2*(nf+2) stack entries per slice)
+#ifndef ENV_SEGNF_SLICE
+#define ENV_SEGNF_SLICE 128
+#endif
+// ENV_SEGNF_SLICE: the per-function LDS arrays (cur, mark, stack) are cut into one slice per walking wave:
+                                // 128 entries (2*(nf+2) stack entries) while nf <= 126, wider slices and fewer walking waves
+                                // beyond (C5 at full size: lists of up to 292 pieces walk on 3 waves instead of 1)
 #ifndef ENV_SEG_EVENT_COST
 #define ENV_SEG_EVENT_COST 320  // what a crossing costs the walk, in regular positions (~5 batches of 64)
 #endif
@@ -1966,6 +1999,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     __shared__ double sg_lastg[ENV_MAXSEG];
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
     int nseg = 1, thstride = j.nthrhmax;
+    // slice of the cursor arrays per walking wave, and how many waves that leaves room for
+    const int slice = (j.nf + 2 <= ENV_SEGNF_SLICE) ? ENV_SEGNF_SLICE : ((j.nf + 2 + 31) / 32) * 32;
+    const int ww = min(min(ENV_BS / WAVE, ENV_MAXWW), ENV_SMALLF / slice);
 #ifdef EGDST_STAMPS2
     unsigned long long s2_ = wall_clock64();
 #define STAMP2(k) do { __syncthreads(); if (tid_ == 0 && j.dbg) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)j.dbg + (k), n_ - s2_); s2_ = n_; } } while (0)
@@ -1980,7 +2016,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         while (nseg > 1 && j.npts < ENV_SEG_MINPTS * nseg) nseg--;  // (a segment should be worth a few batches)
         // every segment writes its rows and thresholds into a region of its own in scratch arrays (rows: up to twice its
         // points plus 64; thresholds: the last 2*nthrhmax entries, thstride per segment)
-        if (j.klog || !j.wM || j.nf > ENV_SEGNF || nseg < 2 ||
+        if (j.klog || !j.wM || ww < 2 || nseg < 2 ||
             2 * (long long)j.npts + 64 * nseg + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap)
             nseg = 1;
         while (nseg > 1 && j.nthrhmax / nseg < 8) nseg--;
@@ -2053,7 +2089,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             }
             sg_p[n] = j.npts;
             sg_n = n;
-            sg_next = min(ENV_BS / WAVE, ENV_MAXWW);  // (the first segments go to the waves in order)
+            sg_next = ww;  // (the first segments go to the waves in order)
         }
         __syncthreads();
         nseg = sg_n;
@@ -2062,13 +2098,13 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     if (nseg > 1) {
         double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
         // (every thread owns a copy of the context: a wave points its own at the segment it has taken)
-        for (int sgi = wave_; wave_ < ENV_MAXWW && sgi < nseg;) {
+        for (int sgi = wave_; wave_ < ww && sgi < nseg;) {
             const int p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
             const size_t row0 = 2 * (size_t)p0 + 64 * (size_t)sgi;
-            e.cur = j.cur + wave_ * ENV_SEGNF_SLICE;
-            e.mark = j.mark + wave_ * ENV_SEGNF_SLICE;
-            e.stack = j.stack + wave_ * 2 * ENV_SEGNF_SLICE;
-            e.stackcap = 2 * ENV_SEGNF_SLICE;
+            e.cur = j.cur + wave_ * slice;
+            e.mark = j.mark + wave_ * slice;
+            e.stack = j.stack + wave_ * 2 * slice;
+            e.stackcap = 2 * slice;
             e.og = j.wM + row0, e.ov = j.wV + row0, e.oc = j.wC + row0;
             e.ocap = 2 * (p1 - p0) + 64;
             e.oth = wTH + (size_t)sgi * thstride, e.oix = wIX + (size_t)sgi * thstride;
@@ -2087,7 +2123,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #if !defined(EGDST_STAMPS2) && !defined(EGDST_STAMPS5)
                 atomicMax((unsigned long long *)j.dbg + 0, d_);
 #endif
+#ifndef EGDST_STAMPS2_WHY
                 atomicAdd((unsigned long long *)j.dbg + 1, d_);
+#endif
             }
 #endif
             int nx = 0;
@@ -2153,9 +2191,12 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #ifdef EGDST_STAMPS2
     __syncthreads();
     if (tid_ == 0 && j.dbg) {  // diagnostic: walks by one wave -- ticks, (<<40) how many, (<<52) how many of them not for being short
-        const int why = j.klog ? 1 : !j.wM ? 2 : j.nf > ENV_SEGNF ? 3 : j.npts < 2 * ENV_SEG_MINPTS ? 4 :
+        const int why = j.klog ? 1 : !j.wM ? 2 : ww < 2 ? 3 : j.npts < 2 * ENV_SEG_MINPTS ? 4 :
                         (2 * (long long)j.npts + 128 + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap) ? 5 : 6;
         atomicAdd((unsigned long long *)j.dbg + 0, (wall_clock64() - s2_) + (1ull << 40) + ((unsigned long long)(why != 4) << 52));
+#ifdef EGDST_STAMPS2_WHY  // (slot 1 then holds the reasons, 10 bits each, instead of the segments' sum)
+        atomicAdd((unsigned long long *)j.dbg + 1, 1ull << (10 * (why - 1)));
+#endif
     }
 #endif
 }

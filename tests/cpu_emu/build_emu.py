@@ -19,6 +19,13 @@ def build(spec_dir, sanitize=True, env_bs=1, parallel_blocks=False, wave=1, fix_
     cmd = ['g++', '-x', 'c++', '-std=c++17', '-O1', '-g', '-mfma', '-ffp-contract=off', '-fPIC', '-shared',
            '-DEGDST_EMU', '-DENV_SEG_MINPTS=%d' % (4 * wave), '-DWAVE=%d' % wave, '-DGRID_BS=1', '-DENV_BS_EMU=%d' % env_bs, '-DFIX_BS=%d' % (1 if parallel_blocks else fix_waves * wave), '-pthread', '-I', HERE, '-I', spec_dir, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
            '-Wno-unused-function', os.path.join(CSRC, 'egdst_kernels.hip'), '-o', out]
+    extra = os.environ.get('EMU_EXTRA_FLAGS', '').split()  # e.g. -DENV_SEGNF_SLICE=4: wide cursor slices with few pieces
+    if extra:
+        cmd[1:1] = extra
+        out = out.replace('.so', '_' + ''.join(c if c.isalnum() else '_' for c in ''.join(extra)) + '.so')
+        cmd[-1] = out
+        if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
+            return out
     if os.environ.get('EMU_SEQ_WALK'):
         cmd[1:1] = ['-DEGDST_SEQ_WALK']
         out = out.replace('.so', '_seqwalk.so')
