@@ -1998,7 +1998,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     __shared__ int sg_p[ENV_MAXSEG + 1], sg_oi[ENV_MAXSEG], sg_oj[ENV_MAXSEG], sg_err[ENV_MAXSEG], sg_pm[ENV_MAXSEG], sg_n, sg_next;
     __shared__ double sg_lastg[ENV_MAXSEG];
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
-    int nseg = 1, thstride = j.nthrhmax;
+    int nseg = 1, thstride = j.nthrhmax, thcap = j.nthrhmax;
     // slice of the cursor arrays per walking wave, and how many waves that leaves room for
     const int slice = (j.nf + 2 <= ENV_SEGNF_SLICE) ? ENV_SEGNF_SLICE : ((j.nf + 2 + 31) / 32) * 32;
     const int ww = min(min(ENV_BS / WAVE, ENV_MAXWW), ENV_SMALLF / slice);
@@ -2015,12 +2015,15 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         nseg = (ENV_BS / WAVE >= 2) ? ENV_MAXSEG : 1;
         while (nseg > 1 && j.npts < ENV_SEG_MINPTS * nseg) nseg--;  // (a segment should be worth a few batches)
         // every segment writes its rows and thresholds into a region of its own in scratch arrays (rows: up to twice its
-        // points plus 64; thresholds: the last 2*nthrhmax entries, thstride per segment)
-        if (j.klog || !j.wM || ww < 2 || nseg < 2 ||
-            2 * (long long)j.npts + 64 * nseg + 2 * (long long)j.nthrhmax + 2 > (long long)j.wcap)
-            nseg = 1;
-        while (nseg > 1 && j.nthrhmax / nseg < 8) nseg--;
-        thstride = j.nthrhmax / nseg;
+        // points plus 64; thresholds: the last 2*thcap entries, thstride per segment -- nthrhmax of them when there is
+        // room, fewer otherwise: a segment that runs out of its share only sends the walk back to one wave)
+        if (j.klog || !j.wM || ww < 2 || nseg < 2) nseg = 1;
+        {
+            const long long room = ((long long)j.wcap - 2 * (long long)j.npts - 64 * nseg - 2) / 2;
+            thcap = (int)(room < (long long)j.nthrhmax ? (room > 0 ? room : 0) : (long long)j.nthrhmax);
+        }
+        while (nseg > 1 && thcap / nseg < 8) nseg--;
+        thstride = thcap / nseg;
         if (j.noseg) nseg = 1, thstride = j.nthrhmax;
     }
 #endif
@@ -2096,7 +2099,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     }
     STAMP2(3);  // planning: cost scan, cuts
     if (nseg > 1) {
-        double *const wTH = j.wM + (j.wcap - 2 * (size_t)j.nthrhmax), *const wIX = wTH + j.nthrhmax;
+        double *const wTH = j.wM + (j.wcap - 2 * (size_t)thcap), *const wIX = wTH + thcap;
         // (every thread owns a copy of the context: a wave points its own at the segment it has taken)
         for (int sgi = wave_; wave_ < ww && sgi < nseg;) {
             const int p0 = sg_p[sgi], p1 = sg_p[sgi + 1];
