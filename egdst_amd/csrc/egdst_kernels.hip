@@ -1519,6 +1519,79 @@ static __device__ __forceinline__ void eg_rank_classify_run(int i0, int n, int n
     }
 }
 
+// Exactly two non-empty lists (the primary envelope of a two-choice model, a choice list with one fold): a MERGE PATH instead
+// of one binary search per point.  Thread t owns the sorted positions [t*C, (t+1)*C): one binary search along its diagonal
+// finds how many points of either list precede them, then it merges its C points one after the other, which reads each key
+// once and in order (C2's 2000-point primary: 11 + 4 dependent LDS reads per thread instead of 4 x 14; C5's 65 536-point
+// streams in global memory: 16 + 128 mostly sequential reads instead of 128 x 6 dependent round trips).  At every point the
+// merge knows how many points of the OTHER list precede it and holds that list's neighbouring pair of keys, which is all the
+// class word needs (same arithmetic as eg_rank_classify_run).  emit(r, i, f, m, v, w): sorted position, input index,
+// function, keys, class word.
+template <class KP, class KPV, class ANA, class EMIT>
+static __device__ __forceinline__ void eg_merge2_classify(int npts, int nf, int ga, int sa, int na, int gb, int sb, int nb, KP Km, KPV Kv,
+                                                         bool cls_on, double kbound, ANA ana, EMIT emit)
+{
+    const int C = (npts + ENV_BS - 1) / ENV_BS;
+    const int d0 = min(npts, (int)threadIdx.x * C), d1 = min(npts, d0 + C);
+    if (d0 >= d1) return;
+    int lo = max(0, d0 - nb), hi = min(d0, na);
+    while (lo < hi) {  // fewest points of A among the first d0 such that A[lo] does not precede B[d0-1-lo]
+        const int mid = (lo + hi) >> 1, ia = sa + mid, ib = sb + d0 - 1 - mid;
+        if (pt_before(Km[ia], Kv[ia], ga, ia, Km[ib], Kv[ib], gb, ib))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    int a = lo, b = d0 - lo;
+    double ma = 0, va = 0, mb = 0, vb = 0, pma = 0, pva = 0, pmb = 0, pvb = 0;  // current and previous keys of the lists
+    if (a < na) ma = Km[sa + a], va = Kv[sa + a];
+    if (b < nb) mb = Km[sb + b], vb = Kv[sb + b];
+    if (a > 0) pma = Km[sa + a - 1], pva = Kv[sa + a - 1];
+    if (b > 0) pmb = Km[sb + b - 1], pvb = Kv[sb + b - 1];
+    for (int r = d0; r < d1; r++) {
+        const bool takeA = (b >= nb) || (a < na && pt_before(ma, va, ga, sa + a, mb, vb, gb, sb + b));
+        // the point, and the other list: its function, how many of its points precede the point, its length, its pair of keys
+        const double m = takeA ? ma : mb, v = takeA ? va : vb;
+        const int f = takeA ? ga : gb, i = takeA ? sa + a : sb + b, g = takeA ? gb : ga;
+        const int cnt = takeA ? b : a, dg = takeA ? nb : na;
+        const double k0m = takeA ? pmb : pma, k0v = takeA ? pvb : pva, k1m = takeA ? mb : ma, k1v = takeA ? vb : va;
+        int w = 0;
+        if (cls_on) {
+            bool force = false;
+            if (cnt >= dg)
+                force = true;  // g has no point ahead: cannot happen below the bound
+            else {
+                double t;
+                if (cnt >= 1) {  // env_fn_cnt on the keys: the segment between g's points cnt-1 and cnt
+                    if (m == k0m)
+                        t = k0v;
+                    else if (m < k0m || m > k1m)
+                        t = -INFINITY;
+                    else
+                        t = k1v * (m - k0m) / (k1m - k0m) + k0v * (k1m - m) / (k1m - k0m);
+                } else
+                    t = ana(g, m);
+                if (v < t) w |= 1;
+                if (t < v && nf <= 29) w |= (2 << g);
+            }
+            if (force || !(m < kbound))
+                w = ENV_CLS_FORCE;
+            else if (nf > 29)
+                w |= ENV_CLS_NOMASK;
+        }
+        emit(r, i, f, m, v, w);
+        if (takeA) {
+            pma = ma, pva = va;
+            a++;
+            if (a < na) ma = Km[sa + a], va = Kv[sa + a];
+        } else {
+            pmb = mb, pvb = vb;
+            b++;
+            if (b < nb) mb = Km[sb + b], vb = Kv[sb + b];
+        }
+    }
+}
+
 // Sort npts points of nf functions (function f occupies [fstart[f], fstart[f]+dims[f]) of the input) into
 // (om,oc,ov,of) and record rank[].  Each function's list is normally already ordered, so the rank of a point
 // is a sum of binary searches (a merge); an unordered list falls back to counting.
@@ -1592,7 +1665,34 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
             }
         *fused = 1;
     }
-    for (int i0 = ENV_RK * (int)threadIdx.x; i0 < npts && !bad; i0 += ENV_RK * ENV_BS) {  // a run of consecutive points per round
+    // two non-empty lists: merge path (eg_merge2_classify); otherwise one search per point and foreign list
+    int nact = 0, ga = -1, gb = -1;
+    for (int g = 0; g < nf; g++)
+        if (dims[g] > 0) {
+            if (nact == 0) ga = g;
+            if (nact == 1) gb = g;
+            nact++;
+        }
+#ifndef EGDST_MERGE2_GLOBAL  // (measured on C5 x 128: 3.95 s with the merge path in global memory against 3.69 s without -- a
+    nact = 0;                // thread's 128 dependent steps cost more there than its 128 searches; LDS-resident streams only)
+#endif
+    if (!bad && nact == 2) {
+        auto emit = [&](int r, int i, int f, double m, double v, int w) {
+            if (cls) cls[r] = w;
+            rank[i] = r;
+            om[r] = m;
+            oc[r] = ic[i];
+            ov[r] = v;
+            of[r] = f;
+        };
+        if (lds_keys)
+            eg_merge2_classify(npts, nf, ga, (int)fstart[ga], (int)dims[ga], gb, (int)fstart[gb], (int)dims[gb], (const eg_ldsd *)lkeys, iv,
+                               cls != nullptr, kbound, ana, emit);
+        else
+            eg_merge2_classify(npts, nf, ga, (int)fstart[ga], (int)dims[ga], gb, (int)fstart[gb], (int)dims[gb], im, iv, cls != nullptr,
+                               kbound, ana, emit);
+    }
+    for (int i0 = ENV_RK * (int)threadIdx.x; i0 < npts && !bad && nact != 2; i0 += ENV_RK * ENV_BS) {  // a run of consecutive points per round
         double m[ENV_RK], v[ENV_RK], c[ENV_RK];
         int f[ENV_RK], r[ENV_RK], w[ENV_RK];
         const int n = min(ENV_RK, npts - i0);
@@ -1734,7 +1834,26 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
                 }
             *fused = 1;
         }
-        for (int i0 = ENV_RK * tid; i0 < npts && !bad; i0 += ENV_RK * ENV_BS) {  // a run of ENV_RK consecutive points per round
+        int nact = 0, ga = -1, gb = -1;  // two non-empty lists: merge path (eg_merge2_classify)
+        for (int g = 0; g < nf; g++)
+            if (dims[g] > 0) {
+                if (nact == 0) ga = g;
+                if (nact == 1) gb = g;
+                nact++;
+            }
+#ifdef EGDST_NO_MERGE2
+        nact = 0;
+#endif
+        if (!bad && nact == 2) {
+            auto emit = [&](int r, int i, int f, double m, double v, int w) {
+                if (cls) cls[r] = w;
+                Lf[r] = f;
+                Lp[i] = r;
+            };
+            eg_merge2_classify(npts, nf, ga, (int)fstart[ga], (int)dims[ga], gb, (int)fstart[gb], (int)dims[gb], Km, Kv, cls != nullptr,
+                               kbound, ana, emit);
+        }
+        for (int i0 = ENV_RK * tid; i0 < npts && !bad && nact != 2; i0 += ENV_RK * ENV_BS) {  // a run of ENV_RK consecutive points per round
             double m[ENV_RK], v[ENV_RK];
             int f[ENV_RK], r[ENV_RK], w[ENV_RK];  // (w: class words)
             const int n = min(ENV_RK, npts - i0);
@@ -2639,7 +2758,12 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(
         } else {
             int *gcls = b.gcls + wo;  // class words of the sorted stream
             blk_rank_sort(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, job.dbg, gcls, &fused,
-                          ana, R1, 4 * lcap);
+                          ana, R1,
+#ifdef EGDST_EMU
+                          lcap);      // (the harness keeps poisoned gaps between the LDS regions: the keys stay in the first)
+#else
+                          4 * lcap);  // (all of the dynamic LDS, as doubles)
+#endif
             if (s_oob) ENV_FAIL(2714);
             {
                 int we = 0, wn = 0, wm = 0;

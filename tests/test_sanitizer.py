@@ -29,6 +29,21 @@ def test_device_code_is_asan_clean_and_bit_exact(args):
 
 
 @pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('args,lcap', [(['retirement2', 'T=8, ngridm=60'], '16'), (['retirement8', 'T=5, ngridm=30, ny=3'], '64'),
+                                       (['occ3', 'T=6, ngridm=30, ngridmax=100'], '64')])
+def test_global_memory_streams_are_asan_clean_and_bit_exact(args, lcap):
+    """EGDST_LCAP: so little LDS that every stream sorts and walks in global memory -- the merge path of two lists, the rank
+    merge with its keys (or, beyond their capacity, a sampled index of them) in LDS, multi-lane waves, segmented walks."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_LCAP=lcap,
+               EMU_WAVE='4', EMU_ENV_BS='8')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py')] + args, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
 def test_the_round1_fault_case_is_clean_with_every_array_in_its_own_allocation():
     """Round 1 saw a GPU memory fault in k_envelope on this very input (8-state model, T=12, ngridm=150, ny=5: 14 492
     rows, 401 608 evaluations) in builds whose walk was NOT inlined.  Under the harness every device array is its own
