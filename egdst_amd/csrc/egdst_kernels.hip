@@ -41,7 +41,7 @@
 #define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
 #endif
 #ifndef EG_SEQ_AFTER_RESEND
-#define EG_SEQ_AFTER_RESEND 4  // k_fixup: guesses evaluated one at a time after a c1<=0 resend
+#define EG_SEQ_AFTER_RESEND 1  // k_fixup: guesses evaluated one at a time after a c1<=0 resend (C2 x 4096: 0 or 1: 225 ms, 2-8: 228 ms)
 #endif
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
