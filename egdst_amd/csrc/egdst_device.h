@@ -42,6 +42,7 @@ struct Batch {
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
     unsigned *work;      // [ndraw] re-basing calls of the draw's guess streams in this solve (straggler detection)
+    int sorted_valid;    // 1: k_sortcheck has filled tsorted for the tables of the next period before the kernels of this period
     unsigned *nregen;    // [ndraw] guess streams of the draw that k_fixup regenerated in this solve (schedule: such draws share groups)
     const double *par;   // [ndraw][MS_NPARAM]
     const double *qw;    // [ny] weights
@@ -210,13 +211,15 @@ static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw,
 }
 
 // Next-period value at nxt->cash (valuefunc, egdst_solver.c:755-772 with linter_extrap, egdst_lib.c:179-206).
-template <class TT> static __device__ __forceinline__ double eg_next_value(const ms_env *E, const TT &t, const ms_pv *nxt)
+// ibr: -1, or the bracket linter's search found for the same x over (M, len) when the column is known to be non-decreasing
+// and len >= 4: valuefunc's search over the column shifted by one row then follows from it (k_grid_lds, eg_second_bracket).
+template <class TT> static __device__ __forceinline__ double eg_next_value(const ms_env *E, const TT &t, const ms_pv *nxt, int ibr = -1)
 {
     const double evf1 = t.V[0], a0 = E->a0, x = nxt->cash;
     if (x < t.M[1] && evf1 > -INFINITY) return ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
     const auto g = t.M + 1, f = t.V + 1;
     const int n = t.len - 1;
-    int i = eg_bracket(x, g, n, 0);
+    int i = (ibr >= 0) ? ((x < t.M[2]) ? 0 : ((x >= t.M[t.len - 2]) ? t.len - 3 : ibr - 1)) : eg_bracket(x, g, n, 0);
     double f0 = f[i], f1 = f[i + 1];
     if (!isfinite(f0)) return f0;
     if (!isfinite(f1)) return f1;
@@ -230,9 +233,10 @@ template <class TT> static __device__ __forceinline__ double eg_next_value(const
 
 // One (next state, shock node) term of the expectation: the body at egdst_solver.c:548-570.
 // Returns c1; on c1>0 fills the two weighted terms.  nxt->ist/shock must be set; fills nxt->cash, nxt->id.
+// sorted: the table's M column is known to be non-decreasing (k_sortcheck) -- one bracket search serves both interpolations.
 template <class TT>
 static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, const ms_pv *cur, ms_pv *nxt,
-                                                 double pr1, int keep, double *t_rhs, double *t_evf)
+                                                 double pr1, int keep, double *t_rhs, double *t_evf, int sorted = 0)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const int n1 = t.len;
@@ -247,7 +251,7 @@ static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, c
     else
         nxt->id = 0;
     *t_rhs = pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
-    if (keep == 1) *t_evf = pr1 * eg_next_value(E, t, nxt);
+    if (keep == 1) *t_evf = pr1 * eg_next_value(E, t, nxt, (sorted && n1 >= 4) ? i : -1);
     return c1;
 }
 

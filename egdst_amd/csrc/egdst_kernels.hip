@@ -200,6 +200,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
             status = -2707;
             break;
         }
+        const int tsorted = b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + nxt.ist] : 0;  // (k_sortcheck ran this period)
         for (int iy = 0; iy < niy; iy++) {
             double pr1;
             if (niy == 1) {
@@ -214,7 +215,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
             checksum += pr1;
             cnt++;
             double t_rhs, t_evf;
-            c1 = eg_term(E, t, cur, &nxt, pr1, 1, &t_rhs, &t_evf);
+            c1 = eg_term(E, t, cur, &nxt, pr1, 1, &t_rhs, &t_evf, tsorted);
             if (c1 <= 0) break;
             rhs += t_rhs;
             evf += t_evf;
@@ -297,6 +298,7 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
         }
         if (t.len < 2) return -10;
         if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
+        const int tsorted = b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + ist1] : 0;  // (k_sortcheck ran this period)
         for (int base = 0; base < niy && status == 0; base += GW) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
@@ -310,7 +312,7 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
                     pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nl, &terr);
                     pr1 *= b.qw[iy];
                 }
-                if (pr1 != 0.0) c1 = eg_term(E, t, cur, &nl, pr1, keep, &t_rhs, &t_evf);
+                if (pr1 != 0.0) c1 = eg_term(E, t, cur, &nl, pr1, keep, &t_rhs, &t_evf, tsorted);
                 shock = nl.shock;
                 cash = nl.cash;
             }
