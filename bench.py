@@ -275,7 +275,13 @@ def main():
         avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
         bytes_per_launch = algbytes / max(klaunch[dom], 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        pm = pmc_metrics(args.workload, chunk, 'k_' + names[dom]) if not args.small else {}
+        # (the grid step has three forms: the counters are those of the one the committed passes of this configuration saw)
+        dom_kernel, pm = 'k_' + names[dom], {}
+        for cand in ({'grid': ['k_grid_lds', 'k_grid_wide', 'k_grid']}.get(names[dom], ['k_' + names[dom]]) if not args.small else []):
+            pm = pmc_metrics(args.workload, chunk, cand)
+            if pm:
+                dom_kernel = cand
+                break
         out = {
             'metric': 'EGM grid-point x shock evals/sec (batched backward induction, all draws, all periods)',
             'value': ev_exec_all / dt_max, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
@@ -294,7 +300,7 @@ def main():
             'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())) if solver else {},
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
             'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(names, kms)},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + names[dom], 'achieved': achieved, 'peak': 8000.0,
+            'roofline': {'bound': 'hbm', 'kernel': dom_kernel, 'achieved': achieved, 'peak': 8000.0,
                          'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
                          'launches': int(klaunch[dom]), 'valu_util': pm.get('valu_util'),
