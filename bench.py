@@ -20,13 +20,21 @@ contributions are reduced with one RCCL all-reduce.  Rank 0 prints ONE JSON line
 value       = evaluations EXECUTED for the draws that solved (failed draws and the evaluations the device credits
               without executing -- include/egdst.h egdst_get_evals_credited -- are left out), all ranks, all timed
               steps / max-over-ranks wall time.  `evals_reference_per_step` is what the reference would count.
-roofline    = algorithmic table bytes per launch of the dominant kernel / its mean HIP-event duration (events on the
-              group streams the kernel is launched on), against the 8 TB/s HBM3E peak; `traffic`, `valu_util`,
+roofline    = algorithmic table bytes per launch of the dominant kernel class / its mean HIP-event duration (events on the
+              group streams the kernels are launched on), against the 8 TB/s HBM3E peak; `traffic`, `valu_util`,
               `valu_fp64_util`, `lds_GBps` from the rocprofv3 --pmc passes committed under profiles/ for this very
               configuration (counters cannot be read from inside the process).  The path is NOT HBM-bound at these
-              sizes (SURVEY.md section 8d says so): the fraction is reported as it is.
+              sizes (SURVEY.md section 8d says so): the fraction is reported as it is, and `ceilings` says what does bind:
+              `egm_only_evals_per_s` = the evaluations of the step / the summed device time of the grid kernel alone (what
+              the step would deliver if the EGM evaluations were all there is), `pipeline_frac_of_egm_only` = value / that,
+              and the issue-slot figures of the grid kernel from the counter passes.
+legs        = (N = 1) one warm-up and one timed step each of the per-GPU shares of the stress configurations BASELINE.json
+              names (C4 x 32 draws, C5 x 128 draws at full size) and of C2 on the surveyed credit limit a0 = -5 (4096 draws,
+              failures counted), each with its own roofline; (N > 1) `strong`: one timed step of the north_star's batches
+              (C5 x 1024, C4 x 256 draws) sharded over the N ranks.
 cpu_baseline= the CPU oracle (oracle/egdst_oracle.c, glibc math, gcc -O2) on a bounded sample of the same draws, timed in
-              this run on the GPU box's host: one thread (`value`, `cores` = 1) and all host cores, one process per draw.
+              this run on the GPU box's host: one thread (`value`, `cores` = 1) and every core this process may use
+              (scheduler affinity and cgroup quota), one process per core.
 """
 import argparse
 import json
@@ -73,6 +81,26 @@ def cpu_model_name():
     return 'unknown'
 
 
+def usable_cores():
+    """cores this process may really use: scheduler affinity, capped by the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(wl, kw, draws, budget_s=10.0, cores=None):
     """Oracle (the 'port' of the reference CPU path) on a bounded sample: one thread, then one process per core."""
     import multiprocessing as mp
@@ -80,7 +108,8 @@ def cpu_baseline(wl, kw, draws, budget_s=10.0, cores=None):
     out = {'value': ev / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
            'sample': '%d draws of the same workload, %.1f s, oracle/egdst_oracle.c gcc -O2 glibc math' % (n, dt),
            'wall_s_per_solve': dt / max(n, 1), 'cpu_model': cpu_model_name(), 'host_cores': os.cpu_count()}
-    cores = cores or min(os.cpu_count() or 1, 16)
+    cores = cores or max(1, min(usable_cores(), len(draws)))
+    out['usable_cores'] = usable_cores()
     if cores > 1:
         parts = [draws[i::cores] for i in range(cores)]
         t0 = time.perf_counter()
@@ -114,6 +143,95 @@ def pmc_metrics(workload, ndraw, kernel):
     except (OSError, ValueError):
         return {}
 
+def pmc_for(workload, ndraw, cls, small=False):
+    """(kernel name, counter figures) of a profile class from the committed PMC passes of this configuration"""
+    cands = {1: ['k_grid_lds', 'k_grid_wide', 'k_grid'], 2: ['k_tp_walk', 'k_envelope'], 0: ['k_probe'], 3: ['k_fixup']}[cls]
+    if not small:
+        for cand in cands:
+            pm = pmc_metrics(workload, ndraw, cand)
+            if pm:
+                return cand, pm
+    return cands[0], {}
+
+
+CLASS_NAMES = ['probe', 'grid', 'envelope', 'regeneration']
+
+
+def roofline_record(workload, ndraw, kms, klaunch, algbytes, evals_step, value, small=False):
+    """the `roofline` object of one configuration from the HIP-event profile of its last solve"""
+    dom = int(np.argmax(kms))
+    avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
+    bytes_per_launch = algbytes / max(klaunch[dom], 1)
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    dom_kernel, pm = pmc_for(workload, ndraw, dom, small)
+    _, pg = pmc_for(workload, ndraw, 1, small)
+    egm_only = evals_step / (kms[1] * 1e-3) if kms[1] > 0 else None
+    return {'bound': 'hbm', 'bound_note': 'reported against HBM as the contract asks; the path is latency / issue bound, see ceilings',
+            'kernel': dom_kernel, 'kernel_class': CLASS_NAMES[dom], 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+            'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
+            'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches': int(klaunch[dom]),
+            'valu_util': pm.get('valu_util'), 'valu_fp64_util': pm.get('valu_fp64_util'), 'lds_GBps': pm.get('lds_GBps'),
+            'wave_cycles_waiting_frac': pm.get('wave_cycles_waiting_frac'), 'counters_from': pm.get('source'),
+            'ceilings': {'egm_only_evals_per_s': egm_only,
+                         'pipeline_frac_of_egm_only': (value / egm_only) if egm_only else None,
+                         'grid_kernel_ms_summed': float(kms[1]),
+                         'grid_kernel_issue_util': pg.get('valu_util'), 'grid_kernel_fp64_util': pg.get('valu_fp64_util'),
+                         'grid_kernel_fp64_share_of_valu': (pg['valu_fp64_util'] / pg['valu_util']) if pg.get('valu_util') else None}}
+
+
+def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None, chunk=None, sync=None, counters_as=None):
+    """One warm-up and one timed step of `ndraw` draws of a workload through one handle of `chunk` draws (default: all of
+    them): the per-GPU share of a stress configuration.  Returns the leg's record."""
+    import torch
+    from egdst_amd import build, parallel, runtime, workloads
+    if model is None:
+        model, drawgen = workloads.WORKLOADS[workload]()
+    chunk = min(chunk or ndraw, ndraw)
+    flags = workloads.BATCH_BUILD_FLAGS.get(workload, []) if chunk >= workloads.BATCH_BUILD_MIN_DRAWS.get(workload, 1 << 30) else []
+    lib = build.build_model(model, extra_flags=flags)
+    desc = model.descriptor()
+    if params is None:
+        params = drawgen(ndraw) if drawgen else np.tile(model.param_vector(), (ndraw, 1))
+    plan = parallel.plan_chunks(ndraw, chunk)
+    solver = runtime.Solver(lib, desc, ndraw=chunk, keep_history=False)
+    rec = {}
+    for timed in (False, True):
+        if timed:
+            solver.set_profile(True)
+        if sync:
+            sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_ref = ev_exec = nfail = 0
+        for c0, valid in plan:
+            p = params[c0:c0 + valid]
+            if valid < chunk:
+                p = np.concatenate([p, np.repeat(p[:1], chunk - valid, axis=0)])
+            solver.set_params(p)
+            solver.solve_async()
+            solver.sync(raise_on_error=False)
+            st, per, cred = solver.status()[0], solver.evals()[1], solver.evals_credited()
+            ok = st[:valid] == 0
+            ev_ref += int(per[:valid].sum())
+            ev_exec += int((per[:valid] - cred[:valid])[ok].sum())
+            nfail += int((~ok).sum())
+        if sync:
+            sync()
+        dt = time.perf_counter() - t0
+        rec = {'dt': dt, 'ev_ref': ev_ref, 'ev_exec': ev_exec, 'nfail': nfail}
+    kms, klaunch, algbytes = solver.profile()   # of the last chunk's solve
+    solver.close()
+    value = rec['ev_exec'] / rec['dt']
+    out = {'workload': label or '%s x %d draws' % (workload, ndraw), 'ndraw': ndraw, 'chunk': chunk, 'build_flags': flags,
+           'ms_per_step': rec['dt'] * 1e3, 'value': value, 'unit': 'evals/s', 'evals_executed': rec['ev_exec'],
+           'evals_reference': rec['ev_ref'], 'failed_draws': rec['nfail'],
+           'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
+           'config': 'T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (desc['T'], desc['ngridm'], desc['ny'], lib.info.nd,
+                                                                                   lib.info.nst, desc['a0'], desc['mmax'])}
+    out['roofline'] = roofline_record(counters_as or workload, chunk, kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value)
+    out['_raw'] = rec
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -131,6 +249,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-single-solve', action='store_true', help='skip the one-draw latency legs (profiling runs)')
     ap.add_argument('--no-extras', action='store_true', help='skip the copy-peak, export and estimation legs')
+    ap.add_argument('--no-legs', action='store_true', help='skip the legs of the stress configurations (C4 x 32, C5 x 128, C2 a0=-5; N > 1: the strong-scaling batches)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -248,7 +367,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(3), np.zeros(3, dtype=np.int32), 0)   # of the LAST solve
+    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(4), np.zeros(4, dtype=np.int32), 0)   # of the LAST solve
     # ---- final objective reduce: the only collective of the path (RCCL over xGMI when world > 1) -----------------
     last = obj[nsteps_all - 1, :mine_n, 0] if mine_n else torch.zeros(0, dtype=torch.float64, device='cuda')
     okmask = ~torch.isnan(last)
@@ -267,21 +386,38 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
     ev_ref_all, ev_exec_all, nfail_all, ndone_all = [float(x) for x in cnt.tolist()]
+    main_extra = {'capacity_retries': solver.capacity_retries if solver else 0,
+                  'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())) if solver else {},
+                  'envelope_cells_by_throughput_path': solver.tp_stats().sum(axis=0).tolist() if solver else None}
+
+    # ---- N > 1: the north_star's batches, strong scaling -- one timed step of C5 x 1024 and of C4 x 256 draws sharded over the
+    # ranks (contiguous shards, chunks that fit HBM through one handle, no collective but the timing barriers over gloo)
+    want_legs = not args.no_legs and not args.small and args.workload == 'C2' and args.scaling == 'weak' and args.rows_cap == 0
+    strong = None
+    if want_legs and world > 1:
+        if solver:
+            solver.close()
+            solver = None
+        torch.cuda.empty_cache()
+        strong = {}
+        for wl, total, ch in (('C5', 1024, 128), ('C4', 256, 32)):
+            lo2, hi2 = parallel.shard_bounds(total, world, rank)
+            m2, gen2 = workloads.WORKLOADS[wl]()
+            rec = timed_leg(wl, hi2 - lo2, model=m2, params=gen2(total)[lo2:hi2], chunk=ch, sync=sync_all) if hi2 > lo2 else None
+            raw = rec['_raw'] if rec else {'dt': 0.0, 'ev_ref': 0, 'ev_exec': 0, 'nfail': 0}
+            t2 = torch.tensor([raw['dt']], dtype=torch.float64)
+            c2 = torch.tensor([float(raw['ev_ref']), float(raw['ev_exec']), float(raw['nfail'])], dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            dist.all_reduce(c2, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                rec.pop('_raw', None)
+                strong['%sx%d' % (wl, total)] = dict(rec, workload='%s x %d draws over %d GPUs (strong scaling, %d per handle)' % (wl, total, world, ch),
+                                                     ndraw=total, draws_rank0=hi2 - lo2, ms_per_step=float(t2.item()) * 1e3,
+                                                     value=float(c2[1].item()) / float(t2.item()), evals_executed=float(c2[1].item()),
+                                                     evals_reference=float(c2[0].item()), failed_draws=float(c2[2].item()), scaling='strong')
 
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
-        names = ['probe', 'grid', 'envelope']
-        dom = int(np.argmax(kms))
-        avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
-        bytes_per_launch = algbytes / max(klaunch[dom], 1)
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # (the grid step has three forms: the counters are those of the one the committed passes of this configuration saw)
-        dom_kernel, pm = 'k_' + names[dom], {}
-        for cand in ({'grid': ['k_grid_lds', 'k_grid_wide', 'k_grid']}.get(names[dom], ['k_' + names[dom]]) if not args.small else []):
-            pm = pmc_metrics(args.workload, chunk, cand)
-            if pm:
-                dom_kernel = cand
-                break
         out = {
             'metric': 'EGM grid-point x shock evals/sec (batched backward induction, all draws, all periods)',
             'value': ev_exec_all / dt_max, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
@@ -296,17 +432,12 @@ def main():
                 'parallelism': 'draws sharded over %d rank(s), no data-path collective, one RCCL all-reduce of the objective' % world},
             'evals_executed_per_step': ev_exec_all / args.steps, 'evals_reference_per_step': ev_ref_all / args.steps,
             'failed_draws_per_step': nfail_all / args.steps, 'draws_per_step': ndone_all / args.steps,
-            'capacity_retries': solver.capacity_retries if solver else 0,
-            'schedule': dict(zip(('groups', 'straggler_lanes', 'straggler_draws'), solver.schedule())) if solver else {},
+            'capacity_retries': main_extra['capacity_retries'], 'schedule': main_extra['schedule'],
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
-            'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(names, kms)},
-            'roofline': {'bound': 'hbm', 'kernel': dom_kernel, 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
-                         'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
-                         'launches': int(klaunch[dom]), 'valu_util': pm.get('valu_util'),
-                         'valu_fp64_util': pm.get('valu_fp64_util'), 'lds_GBps': pm.get('lds_GBps'),
-                         'wave_cycles_waiting_frac': pm.get('wave_cycles_waiting_frac'),
-                         'counters_from': pm.get('source')},
+            'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
+            'envelope_cells_by_throughput_path': main_extra['envelope_cells_by_throughput_path'],
+            'roofline': roofline_record(args.workload, chunk, kms, klaunch, algbytes, ev_exec_all / args.steps / max(world * nchunks, 1),
+                                        ev_exec_all / dt_max, small=args.small),
         }
         one = host_draws[-1][:1] if mine_n else None
         if not args.no_single_solve and world == 1 and mine_n:
@@ -356,6 +487,24 @@ def main():
             torch.cuda.synchronize()
             out['roofline']['hbm_copy_GBps_measured'] = 5 * 2 * a.numel() * 8 / (time.perf_counter() - t1) / 1e9
             del a, b_
+        if strong is not None:
+            out['strong'] = strong
+        if want_legs and world == 1:
+            # the per-GPU shares of the stress configurations and C2 on the surveyed credit limit (see the module docstring)
+            if solver:
+                solver.close()
+                solver = None
+            torch.cuda.empty_cache()
+            from egdst_amd import examples
+            legs = {}
+            legs['C4x32'] = timed_leg('C4', 32, label='C4 x 32 draws: the per-GPU share of BASELINE configs[3] (256 draws over 8 GPUs)')
+            legs['C5x128'] = timed_leg('C5', 128, label='C5 x 128 draws at full size: the per-GPU share of BASELINE configs[4] (1024 draws over 8 GPUs)')
+            m5 = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=-5)
+            legs['c2_a0_minus5_batch'] = timed_leg('C2', args.ndraw, model=m5, params=host_draws[-1], counters_as='C2a0m5',
+                                                   label='C2 with the shipped credit limit a0=-5 (SURVEY section 8d), the same %d draws' % args.ndraw)
+            for v in legs.values():
+                v.pop('_raw', None)
+            out['legs'] = legs
         if not args.no_cpu_baseline and world == 1 and mine_n:   # reported baseline: rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload, wl_kw, host_draws[-1])
             out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']

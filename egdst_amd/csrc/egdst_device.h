@@ -69,6 +69,11 @@ struct Batch {
     int *secn, *secact, *secerr;        // rows of the choice's list, choice active, first error of the job
     double *secev;                      // expected value at a0 of the choice
     unsigned long long *secevals;       // evaluations counted by the job
+    // throughput path of the envelope step (k_tp_*, batches with many cells per period): per (cell, choice) and per cell records
+    struct TpRec *tprec;                // [ndraw*MS_NST*MS_ND]
+    struct TpCell *tpcell;              // [ndraw*MS_NST]
+    unsigned *tpstat;                   // [2*ndraw] cells of the draw the throughput path completed / left to k_envelope, this solve
+    int *tpn, *tplist;                  // [MAX_GROUPS * nt] cells per (group, period) left to k_envelope; [ndraw*MS_NST] their slots, a group's at its first
     // status
     int *status;          // [ndraw] first error code
     int *where;           // [2*ndraw] (it, ist) of that error
@@ -84,7 +89,33 @@ struct Batch {
                                    // period + 24 B per row written + 16 B per threshold
 };
 
+// Kernels do not take the Batch by value: ~600 bytes and ~70 pointers in the kernel-argument segment are loaded into SGPRs
+// at kernel entry and stay live (hipcc 7.2: 765 SGPR spills in k_envelope, 267 in k_fixup, 127 in k_probe -- every spilled
+// SGPR is a lane of a VGPR in kernels that have no VGPR to spare).  The host keeps one copy per draw group in device memory
+// (egdst_host.inc: upload_batches) and kernels read it through the CONSTANT address space: every field is a scalar load
+// (s_load) issued where it is used, invariant, so the register allocator re-loads instead of spilling.
+#ifdef EGDST_EMU
+typedef const Batch &BatchRef;
+#define EG_BATCH_REF(bp) (*(bp))
+#else
+typedef const __attribute__((address_space(4))) Batch &BatchRef;
+#define EG_BATCH_REF(bp) (*(const __attribute__((address_space(4))) Batch *)(bp))
+#endif
+
 struct Env1Scratch;
+#define TP_NF 64   // functions (choices, or the monotone pieces of one choice list) the throughput path of the envelope step keeps
+struct TpRec {     // what k_tp_prep found for one (cell, choice); k_tp_walk (secondary) updates cnt
+    int active;    // the choice is in the choice set
+    int cnt;       // rows of the choice's list in its slice of the p arrays
+    int nfold;     // > 0: the list folds back nfold times -- its pieces (with their extrapolation points) are in the s slice
+    int fused;     // the sort classified the stream (blk_rank_sort: *fused)
+    double evfa0;
+    unsigned long long evals;
+    int fstart[TP_NF];  // first point of every piece in the s slice (function ids id .. id+nfold)
+};
+struct TpCell {    // primary envelope of a cell: what k_tp_sort hands to k_tp_walk
+    int npts, fused;
+};
 struct ProbeOut {
     int active;       // choice is in the choice set (and the state feasible)
     int seq;          // 1: the whole stream was generated sequentially by k_fixup (candidates 0..np-1, all kept)
@@ -196,7 +227,7 @@ template <class PD> struct TabT {
 typedef TabT<const double *> Tab;    // in global memory
 typedef TabT<const eg_ldsd *> TabL;  // M, C, V staged in LDS (k_fixup's sequential stretches)
 
-static __device__ __forceinline__ Tab eg_tab(const Batch &b, int slot, int draw, int ist)
+static __device__ __forceinline__ Tab eg_tab(BatchRef b, int slot, int draw, int ist)
 {
     size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
     Tab t;

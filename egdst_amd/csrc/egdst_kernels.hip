@@ -63,7 +63,7 @@
 #include "../../include/egdst.h"
 
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void eg_fail(const Batch &b, int draw, int it, int ist, int code)
+static __device__ __forceinline__ void eg_fail(BatchRef b, int draw, int it, int ist, int code)
 {
     if (atomicCAS(&b.status[draw], 0, code) == 0) {
         b.where[2 * draw] = it;
@@ -71,7 +71,7 @@ static __device__ __forceinline__ void eg_fail(const Batch &b, int draw, int it,
     }
 }
 
-static __device__ __forceinline__ ms_env eg_env(const Batch &b, int draw)
+static __device__ __forceinline__ ms_env eg_env(BatchRef b, int draw)
 {
     ms_env E;
     E.t0 = b.g.t0;
@@ -86,15 +86,16 @@ static __device__ __forceinline__ ms_env eg_env(const Batch &b, int draw)
     return E;
 }
 
-static __device__ __forceinline__ size_t eg_cand(const Batch &b, int draw, int ist, int id)
+static __device__ __forceinline__ size_t eg_cand(BatchRef b, int draw, int ist, int id)
 {
     return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.Cp;
 }
 
 // ---------------------------------------------------------------------------------------------
 // terminal period (egdst_solver.c:433-476, END2): M_i = trinv(m1 + i (m2-m1)/(ngridm-1)), C = M, V = u(C)
-__global__ void __launch_bounds__(GRID_BS) k_terminal(Batch b, int it)
+__global__ void __launch_bounds__(GRID_BS) k_terminal(const Batch *bp_, int it)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.y;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     const int i = blockIdx.x * GRID_BS + threadIdx.x;
@@ -168,7 +169,7 @@ struct LaneEval {
     double bshock, bcash;
 };
 
-static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms_env *E, const ms_pv *cur, int slot1, int draw,
+static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env *E, const ms_pv *cur, int slot1, int draw,
                                                         double A)
 {
     LaneEval r;
@@ -263,7 +264,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(const Batch &b, const ms
 // work on different guesses and may leave the accumulation loop at different shock nodes -- every shuffle reads a
 // lane of the own group, which is active whenever the reader is).
 template <class TT, int GW = WAVE>
-static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
+static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
                                           double savings, int keep, double *rhs_o, double *evf_o, int *nev,
                                           int *brk_ist, double *brk_shock, double *brk_cash, const TT *lt)
 {
@@ -360,7 +361,7 @@ static __device__ __forceinline__ int eg_wave_expectation(const Batch &b, const 
 //            algorithm; it is used when a zero-consumption resend turns up INSIDE the grid stage
 //            (egdst_solver.c:1080-1099), which re-bases every later guess and cannot be speculated in parallel.
 template <int NW, int full>
-static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, int draw, int ist, int id)
+static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int draw, int ist, int id)
 {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const bool lead = threadIdx.x == 0;  // all NW waves carry the same generator state; one thread writes
@@ -774,8 +775,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(const Batch &b, int it, in
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
+__global__ void __launch_bounds__(WAVE) k_probe(const Batch *bp_, int it)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.x;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
@@ -787,8 +789,9 @@ __global__ void __launch_bounds__(WAVE) k_probe(Batch b, int it)
 // would actually request?  k_fixup_scan (one wave per stream, no LDS) lists those streams; k_fixup (a small grid of
 // 4-wave workgroups with the LDS table buffer) redoes each listed stream sequentially, exactly as the reference does.
 // `cnt` is this (group, period)'s counter, `list` the group's list (one entry per stream at most).
-__global__ void __launch_bounds__(WAVE) k_fixup_scan(Batch b, int it, int *cnt, int *list)
+__global__ void __launch_bounds__(WAVE) k_fixup_scan(const Batch *bp_, int it, int *cnt, int *list)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.x;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     if (b.status[draw]) return;
@@ -819,8 +822,9 @@ __global__ void __launch_bounds__(WAVE) k_fixup_scan(Batch b, int it, int *cnt, 
 #ifndef FIX_MINW
 #define FIX_MINW 1  // (3: at most 168 VGPRs, so that a k_fixup wave fits a SIMD beside two waves of the -DENV_MINW=3 k_envelope)
 #endif
-__global__ void __launch_bounds__(FIX_BS, FIX_MINW) k_fixup(Batch b, int it, const int *cnt, const int *list)
+__global__ void __launch_bounds__(FIX_BS, FIX_MINW) k_fixup(const Batch *bp_, int it, const int *cnt, const int *list)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int n = *cnt;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int combo = list[k];
@@ -836,8 +840,9 @@ __global__ void __launch_bounds__(FIX_BS, FIX_MINW) k_fixup(Batch b, int it, con
 
 // ---------------------------------------------------------------------------------------------
 // Closed-form grid point n (1 <= n <= ngridm-1) and its EGM evaluation; one lane per point.
-__global__ void __launch_bounds__(GRID_BS) k_grid(Batch b, int it)
+__global__ void __launch_bounds__(GRID_BS) k_grid(const Batch *bp_, int it)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.y;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
@@ -1013,8 +1018,9 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
 
 // Is the M column of every next-period table non-decreasing?  One workgroup per (draw, state) of the group, once per
 // period, for the handles whose tables do not fit k_grid_lds' LDS (the staged form checks the order while staging).
-__global__ void __launch_bounds__(GRID_BS) k_sortcheck(Batch b, int it)
+__global__ void __launch_bounds__(GRID_BS) k_sortcheck(const Batch *bp_, int it)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     __shared__ int bad_;
     const int ist = blockIdx.x % MS_NST, draw = b.order[b.draw0 + blockIdx.x / MS_NST];
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
@@ -1032,8 +1038,9 @@ __global__ void __launch_bounds__(GRID_BS) k_sortcheck(Batch b, int it)
 #ifndef GRID_MINW
 #define GRID_MINW 1  // (experiments: waves per SIMD k_grid_lds is compiled for; 8 = at most 64 VGPRs)
 #endif
-__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(Batch b, int it, int lrows)
+__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp_, int it, int lrows)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
     __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded
     __shared__ int gl_stride, gl_ns[MS_NST];  // every gl_stride-th row is staged (1: whole columns); staged entries per state
@@ -1079,7 +1086,7 @@ __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(Batch b, int it
             for (int s1 = 0; s1 < MS_NST; s1++) nfe += gl_off[s1] > 0;
             stride = (tot + lrows - nfe - 1) / max(lrows - nfe, 1);
             for (int s1 = 0; s1 < MS_NST && ok; s1++)
-                if (gl_off[s1] > 0 && !b.tsorted[(size_t)draw * MS_NST + s1]) ok = 0;
+                if (gl_off[s1] > 0 && !(b.sorted_valid && b.tsorted[(size_t)draw * MS_NST + s1])) ok = 0;
         }
         int acc = 0;
         for (int s1 = 0; s1 < MS_NST; s1++) {
@@ -1247,8 +1254,9 @@ __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(Batch b, int it
 #define EG_GW 16
 #define EG_GRIDW_BS 256
 #endif
-__global__ void __launch_bounds__(EG_GRIDW_BS) k_grid_wide(Batch b, int it)
+__global__ void __launch_bounds__(EG_GRIDW_BS) k_grid_wide(const Batch *bp_, int it)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.y;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
     const int n = (blockIdx.x * EG_GRIDW_BS + (int)threadIdx.x) / EG_GW + 1;  // the group's grid point
@@ -2028,7 +2036,9 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
 
 // All threads pre-classify the sorted stream, then wave 0 walks it; results through *err, *n, *nth (valid in wave 0,
 // every lane of it holds the same values)
-template <bool L>
+// SEG = false: the walk is never cut into segments -- the throughput path (k_tp_walk), where a whole cell belongs to one
+// wave and the batch, not the cell, provides the parallelism; the planning, checking and gathering code is compiled out.
+template <bool L, bool SEG = true>
 static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
                                                 const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
                                                 const typename EgMem<L>::S *f, const typename EgMem<L>::S *posl,
@@ -2130,7 +2140,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #define STAMP2(k)
 #endif
 #if !defined(EGDST_SEQ_WALK)
-    {
+    if (SEG) {
         // more segments than waves: the walking waves (at most ENV_MAXWW: the slices of the cursor arrays) take them from
         // a queue, which evens out what the cost estimate below gets wrong
         nseg = (ENV_BS / WAVE >= 2) ? ENV_MAXSEG : 1;
@@ -2148,7 +2158,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         if (j.noseg) nseg = 1, thstride = j.nthrhmax;
     }
 #endif
-    if (nseg > 1) {
+    if (SEG && nseg > 1) {
         // Where to cut: segments of equal COST, not of equal length.  A regular stretch costs ~1/64 of a batch per position,
         // a crossing several batches, and crossings cluster (the folds of a choice list sit in a narrow range of M).  The
         // number of crossings in a stretch is estimated by how often the function of consecutive points that nothing lies
@@ -2219,7 +2229,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         nseg = sg_n;
     }
     STAMP2(3);  // planning: cost scan, cuts
-    if (nseg > 1) {
+    if (SEG && nseg > 1) {
         double *const wTH = j.wM + (j.wcap - 2 * (size_t)thcap), *const wIX = wTH + thcap;
         // (every thread owns a copy of the context: a wave points its own at the segment it has taken)
         for (int sgi = wave_; wave_ < ww && sgi < nseg;) {
@@ -2341,7 +2351,8 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
 #else
 #define ENV_VGPR_ATTR
 #endif
-__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(Batch b, int it, int terminal, int lcap, int pass, int part)
+// bxi: the workgroup's job -- cell slot of the group (part 0, 2) or cell slot * MS_ND + choice (part 1)
+static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int terminal, int lcap, int pass, int part, int bxi)
 {
     EG_DYN_LDS(dynlds);
 #ifdef EGDST_STAMPS5  // diagnostic: residency of the whole workgroup (slot 0), completed cells only
@@ -2353,7 +2364,7 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(
     __shared__ double s_evfa0[MS_ND];
     __shared__ int s_cnt[MS_ND], s_start[MS_ND];
     __shared__ int s_err, s_n, s_m, s_oob;
-    const int bx_ = (part == 1) ? (int)blockIdx.x / MS_ND : (int)blockIdx.x, pid = (part == 1) ? (int)blockIdx.x % MS_ND : 0;
+    const int bx_ = (part == 1) ? bxi / MS_ND : bxi, pid = (part == 1) ? bxi % MS_ND : 0;
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
@@ -2843,6 +2854,415 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(
     }
 }
 
+// pass 0 / 1 / 2: one workgroup per job of the launch.  pass 3: the cells the throughput path (k_tp_*, below) left to this
+// kernel -- `list` holds their slots, *cnt how many; a small grid loops over them, so that a period with no such cell costs
+// a handful of workgroups that return at once instead of one 125-KB-LDS workgroup per cell of the group.
+__global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(const Batch *bp_, int it, int terminal, int lcap, int pass, int part,
+                                                                                const int *list, const int *cnt)
+{
+    BatchRef b = EG_BATCH_REF(bp_);
+    // (ONE inlined copy of the cell's code: the other passes are the loop with a single turn)
+    const int n = (pass == 3) ? *cnt : (int)gridDim.x;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        eg_envelope_cell(b, it, terminal, lcap, pass == 3 ? 1 : pass, part, pass == 3 ? list[k] : k);
+        __syncthreads();  // (the LDS of the cell is reused by the next one)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// THROUGHPUT PATH of the envelope step (models with several choices, batches with many cells per period).
+//
+// k_envelope is built for latency: one workgroup of 512 threads per cell, the cell's stream resident in ~125 KB of LDS,
+// 256 VGPRs -- one workgroup per CU, two waves per SIMD, and the counters of round 2 say what that costs when there are
+// thousands of cells per period: 73 % of the wave cycles waiting, 4 % VALU busy, a whole CU slower than one CPU core on this
+// step (profiles/r02_f_pmc_C2_ndraw4096.csv).  A batch does not need a fast cell, it needs many cells in flight.  The same
+// step as FIVE lean kernels, each with the registers and the LDS of its own phase only, streams in global memory (L2):
+//   k_tp_prep  (cell, choice), 256 threads: stop rule (:1100,1150), keep rule (:634), compaction into the choice's list, fold
+//              detection and the pieces of a folded list with their extrapolation points (envelope2, :776-835);
+//   k_tp_sort  stage 0 (cell, choice with a folded list) / stage 1 (cell), 256 threads: comp1 order (:1240) as ranks from
+//              binary searches over the lists' M keys staged in LDS (8 B per point), class words of the walk alongside
+//              (blk_rank_sort, the code k_envelope uses for streams that do not fit its LDS);
+//   k_tp_walk  stage 0 / stage 1, ONE WAVE per job: the envelope walk (:1285-1532, thresholds :1596-1915) over the sorted
+//              stream, never cut into segments -- the batch provides the parallelism, 12-16 such waves share a CU; stage 1
+//              writes the period's table (saveoutput, :917-952).
+// Nothing new is computed: every phase calls the device functions k_envelope calls, on the same numbers in the same order.
+// The path produces a cell only when everything about it is regular; ANY condition that k_envelope would report as an
+// error, and every limit of this path (more than TP_NF pieces, a failed draw, an infeasible state), sets b.defer[cell] and the
+// cell is done afterwards, from the untouched candidates, by k_envelope itself (pass 1) -- so error codes, their order and
+// the partially written tables of failing draws stay exactly k_envelope's.
+#if MS_ND > 1
+#ifdef EGDST_EMU
+#define TP_BS ENV_BS_EMU  // (the harness sizes the scan scratch of the block-wide helpers by its envelope workgroup)
+#else
+#define TP_BS 256
+#endif
+static_assert(MS_ND <= TP_NF, "TP_NF must hold one function per choice");
+#define TP_DEFER()                            \
+    do {                                      \
+        if (threadIdx.x == 0) b.defer[cell] = 1; \
+        return;                               \
+    } while (0)
+
+#ifndef TP_PREP_MINW
+#define TP_PREP_MINW 1
+#endif
+#ifndef TP_SORT_MINW
+#define TP_SORT_MINW 8  // (at most 64 VGPRs: eight waves per SIMD; the default build came out at 65)
+#endif
+__global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp_, int it)
+{
+    BatchRef b = EG_BATCH_REF(bp_);
+    __shared__ int sh[ENV_MAXBS + 2];
+    __shared__ int s_fstart[TP_NF];
+    __shared__ int s_oob;
+    const int bx_ = (int)blockIdx.x / MS_ND, id = (int)blockIdx.x % MS_ND;
+    const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
+    const int tid = threadIdx.x;
+    const size_t cell = (size_t)draw * MS_NST + ist;
+    TpRec *R = b.tprec + cell * MS_ND + id;
+    if (tid == 0) R->active = 0, R->cnt = 0, R->nfold = 0, R->fused = 0, R->evfa0 = 0.0, R->evals = 0ull, s_oob = 0;
+    if (b.status[draw]) TP_DEFER();  // (k_envelope clears the lengths of a failed draw's cells)
+    ms_env E = eg_env(b, draw);
+    ms_pv cur;
+    cur.it = it, cur.ist = ist, cur.id = 0, cur.cash = cur.savings = cur.shock = 0;
+    if (ms_feasible(&E, &cur) != 1) TP_DEFER();
+    const ProbeOut P = b.probe[cell * MS_ND + id];
+    if (!P.active) return;
+    __syncthreads();
+    const int ngridmax = b.g.ngridmax, ngridm = b.g.ngridm;
+    const double mmax = b.g.mmax;
+    const size_t W = (size_t)b.g.Cp, wo = cell * (size_t)(MS_ND + 1) * b.g.Cp + (size_t)id * b.g.Cp;
+    double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
+    double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
+    int *sF = b.sF + wo;
+    const size_t co = eg_cand(b, draw, ist, id);
+    // ---- stop rule: the first requested point whose returned M stops the stream is itself kept (:1100) -----------------------
+    int nreq = 0, fusedstats = 0;
+    unsigned long long evals = 0;
+    double evfa0 = P.evfa0;
+    if (P.seq) {
+        nreq = P.np - 1;  // k_fixup stored the kept points of the whole stream in order
+        evals = (unsigned long long)P.probe_evals;
+    } else {
+        const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
+        int first = navail + 1;
+        for (int n = 1 + tid; n <= navail; n += TP_BS)
+            if (!(b.cR[co + n] < mmax)) first = min(first, n);
+        first = blk_min(first, sh);
+        nreq = min(first, navail);
+        fusedstats = 1;
+    }
+    // ---- compaction of the kept points (:634) with the statistics of the requested ones -----------------------------------
+    int hard = 0, n12 = 0, ev = 0, cnt = 0;
+    {
+        int carry = 0;
+        for (int base = 0; base <= nreq; base += ENV_CK * TP_BS) {
+            const int n0 = base + ENV_CK * tid;
+            double vM[ENV_CK], vC[ENV_CK], vV[ENV_CK];
+            int keep[ENV_CK], mine = 0;
+#pragma unroll
+            for (int k = 0; k < ENV_CK; k++) {
+                const int n = n0 + k;
+                keep[k] = 0;
+                vM[k] = vC[k] = vV[k] = 0;
+                if (n <= nreq) {
+                    vM[k] = b.cM[co + n], vC[k] = b.cC[co + n], vV[k] = b.cV[co + n];
+                    if (P.seq)
+                        keep[k] = 1;
+                    else if (n == 0)
+                        keep[k] = P.np;
+                    else {
+                        const int st = b.cSt[co + n];
+                        if (st < 0) hard = max(hard, -st);
+                        n12 |= (st == 1) | ((st == 2) << 1);
+                        ev += b.cCnt[co + n];
+                        keep[k] = (st == 0 && isfinite(vM[k]));
+                    }
+                }
+                mine += keep[k];
+            }
+            int tot;
+            int d = carry + blk_scan_int(mine, sh, &tot);
+#pragma unroll
+            for (int k = 0; k < ENV_CK; k++)
+                if (keep[k]) {
+                    if (d < 0 || (size_t)d >= W)
+                        s_oob = 1;
+                    else
+                        pM[d] = vM[k], pC[d] = vC[k], pV[d] = vV[k];
+                    d++;
+                }
+            carry += tot;
+        }
+        cnt = carry;
+    }
+    if (fusedstats) {
+        blk_reduce3(&hard, &n12, &ev, sh);
+        evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
+        if (hard || (n12 & 1)) TP_DEFER();  // a hard error, a zero-consumption signal left over: k_envelope reports them
+        if (n12 & 2) evfa0 = -INFINITY;
+    }
+    __syncthreads();
+    if (s_oob) TP_DEFER();
+    // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -------------------------------------------
+    int nfold = 0;
+    if (cnt > 1) {
+        for (int i = 1 + tid; i < cnt; i += TP_BS)
+            if (pM[i - 1] > pM[i] || pV[i - 1] > pV[i]) nfold++;
+        nfold = blk_sum(nfold, sh);
+    }
+    if (nfold > 0) {
+        if (id + nfold + 1 > TP_NF) TP_DEFER();
+        // the pieces, one constant-extrapolation point appended to every closed one (:822-835)
+        int carry = 0, lastfold = 0;
+        for (int base = 0; base < cnt; base += TP_BS) {
+            const int i = base + tid;
+            int fold = 0;
+            if (i >= 1 && i < cnt) fold = (pM[i - 1] > pM[i] || pV[i - 1] > pV[i]);
+            int tot;
+            const int ex = blk_scan(fold, sh, &tot);
+            if (i < cnt) {
+                const int sidx = carry + ex + fold;  // pieces closed before this point
+                const int d = i + sidx;
+                if ((size_t)d >= W)
+                    s_oob = 1;
+                else {
+                    sM[d] = pM[i], sC[d] = pC[i], sV[d] = pV[i], sF[d] = id + sidx;
+                    if (fold) {
+                        sM[d - 1] = 1.5 * mmax, sC[d - 1] = pC[i - 1], sV[d - 1] = pV[i - 1], sF[d - 1] = id + sidx - 1;
+                        s_fstart[id + sidx] = d;
+                        if (sidx == nfold) lastfold = i;
+                    }
+                }
+                if (i == 0) s_fstart[id] = 0;
+            }
+            carry += tot;
+        }
+        lastfold = blk_sum(lastfold, sh);
+        if (s_oob || lastfold + (nfold - 1) >= ngridmax) TP_DEFER();  // (:823 not enough space: k_envelope reports it)
+        __syncthreads();
+        for (int f = tid; f < id + nfold + 1; f += TP_BS) R->fstart[f] = (f < id) ? 0 : s_fstart[f];
+    }
+    if (tid == 0) R->active = 1, R->cnt = cnt, R->nfold = nfold, R->evfa0 = evfa0, R->evals = evals;
+}
+
+// stage 0: the pieces of one folded choice list (secondary envelope); stage 1: the choice lists of a cell (primary).
+// lkcap: M keys that fit the dynamic LDS.
+__global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap)
+{
+    BatchRef b = EG_BATCH_REF(bp_);
+    EG_DYN_LDS(dynlds);
+    __shared__ int sh[ENV_MAXBS + 2];
+    __shared__ int s_fstart[TP_NF], s_fdims[TP_NF];
+    __shared__ double s_evfa0[MS_ND];
+    __shared__ int s_oob;
+    const int bx_ = stage ? (int)blockIdx.x : (int)blockIdx.x / MS_ND, id = stage ? 0 : (int)blockIdx.x % MS_ND;
+    const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
+    const int tid = threadIdx.x;
+    const size_t cell = (size_t)draw * MS_NST + ist;
+    if (b.defer[cell]) return;  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
+    TpRec *R = b.tprec + cell * MS_ND + id;
+    ms_env E = eg_env(b, draw);
+    const size_t Wcell = (size_t)(MS_ND + 1) * b.g.Cp;
+    const size_t wo = cell * Wcell + (size_t)id * b.g.Cp;
+    double *qM = b.qM + wo, *qC = b.qC + wo, *qV = b.qV + wo;
+    int *qF = b.qF + wo, *rank = b.rank + wo, *gcls = b.gcls + wo;
+    eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
+    if (tid == 0) s_oob = 0;
+    int npts = 0, nf = 0, sec_id = -1;
+    double sec_ev = 0;
+    const double *iM, *iC, *iV;
+    const int *iF;
+    if (stage == 0) {
+        if (!R->active || R->nfold <= 0) return;
+        npts = R->cnt + R->nfold;
+        nf = id + R->nfold + 1;
+        for (int f = tid; f < nf; f += TP_BS) {
+            const int a = R->fstart[f], z = (f + 1 < nf) ? R->fstart[f + 1] : npts;
+            fstart[f] = (f < id) ? 0 : a;
+            fdims[f] = (f < id) ? 0 : z - a;
+        }
+        sec_id = id, sec_ev = R->evfa0;
+        iM = b.sM + wo, iC = b.sC + wo, iV = b.sV + wo, iF = b.sF + wo;
+    } else {
+        // the choice lists packed one after another at the front of the cell's p arrays (choice 0's slice starts there already;
+        // a later list moves down, never past its own start), as part 2 of k_envelope does
+        double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
+        int *pF = b.pF + wo;
+        int any = 0, nall = 0;
+        for (int k = 0; k < MS_ND; k++) {
+            const TpRec *Rk = R + k;
+            const int cntk = Rk->cnt;
+            if (Rk->active) any = 1;
+            if (tid == 0) s_fstart[k] = nall, s_fdims[k] = cntk, s_evfa0[k] = Rk->evfa0;
+            const size_t src = (size_t)k * b.g.Cp;
+            if (k > 0 && cntk > 0 && src != (size_t)nall) {
+                for (int base = 0; base < cntk; base += TP_BS) {  // (chunks: read, barrier, write -- the ranges may overlap)
+                    const int r = base + tid;
+                    double a_ = 0, b2_ = 0, c_ = 0;
+                    if (r < cntk) a_ = pM[src + r], b2_ = pC[src + r], c_ = pV[src + r];
+                    __syncthreads();
+                    if (r < cntk) pM[nall + r] = a_, pC[nall + r] = b2_, pV[nall + r] = c_;
+                    __syncthreads();
+                }
+            }
+            for (int r = tid; r < cntk; r += TP_BS) pF[nall + r] = k;
+            nall += cntk;
+        }
+        if (!any || nall == 0) TP_DEFER();  // (errors 14 and 15 of k_envelope)
+        npts = nall, nf = MS_ND;
+        iM = pM, iC = pC, iV = pV, iF = pF;
+    }
+    __syncthreads();
+    const int sec_id_ = sec_id;
+    const double sec_ev_ = sec_ev;
+    auto ana = [&](int g, double x) -> double {  // value of function g before its first point (env_analytic / env_evf)
+        const double ev = (sec_id_ >= 0) ? (g == sec_id_ ? sec_ev_ : -INFINITY) : s_evfa0[g];
+        if (ev == -INFINITY) return -INFINITY;
+        ms_pv cv;
+        cv.it = it, cv.ist = ist, cv.id = g, cv.cash = cv.savings = cv.shock = 0;
+        return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
+    };
+    int fused = 0;
+    blk_rank_sort(npts, nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw, gcls, &fused, ana,
+                  (eg_ldsd *)dynlds, lkcap);
+    __syncthreads();
+    if (s_oob) TP_DEFER();
+    if (tid == 0) {
+        if (stage == 0)
+            R->fused = fused;
+        else
+            b.tpcell[cell].npts = npts, b.tpcell[cell].fused = fused;
+    }
+}
+
+// One wave per job.  stage 0: secondary envelope of a folded choice list, result written over the list it came from (dead by
+// then: its pieces live in the s slice, the sorted stream in the q slice); stage 1: primary envelope into the period's table.
+#ifndef TP_WALK_MINW
+#define TP_WALK_MINW 1
+#endif
+// stage 1 also lists the cells that are left to k_envelope (`list`, `cnt`: this (group, period)'s; every cell's stage-1
+// workgroup runs exactly once, so a cell is listed exactly once whichever kernel flagged it).
+#define TP_DEFER_LISTED()                                                   \
+    do {                                                                    \
+        if (threadIdx.x == 0) {                                             \
+            b.defer[cell] = 1;                                              \
+            list[atomicAdd((unsigned *)cnt, 1u)] = bx_;                     \
+            atomicAdd(&b.tpstat[2 * draw + 1], 1u);                         \
+        }                                                                   \
+        return;                                                             \
+    } while (0)
+__global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_, int it, int stage, int *list, int *cnt)
+{
+    BatchRef b = EG_BATCH_REF(bp_);
+    __shared__ int sh[ENV_MAXBS + 2];
+    __shared__ int s_fstart[TP_NF], s_fdims[TP_NF], s_fcur[TP_NF], s_fmark[TP_NF];
+    __shared__ int s_stack[2 * (TP_NF + 2)];
+    __shared__ double s_evfa0[MS_ND];
+    const int bx_ = stage ? (int)blockIdx.x : (int)blockIdx.x / MS_ND, id = stage ? 0 : (int)blockIdx.x % MS_ND;
+    const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
+    const int tid = threadIdx.x;
+    const size_t cell = (size_t)draw * MS_NST + ist;
+    if (b.defer[cell]) {
+        if (stage == 1 && tid == 0) list[atomicAdd((unsigned *)cnt, 1u)] = bx_, atomicAdd(&b.tpstat[2 * draw + 1], 1u);
+        return;
+    }
+    TpRec *R = b.tprec + cell * MS_ND + id;
+    if (stage == 0 && (!R->active || R->nfold <= 0)) return;
+    ms_env E = eg_env(b, draw);
+    const int slot = (b.g.nslots == 2) ? (it & 1) : it;
+    const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
+    const size_t Wcell = (size_t)(MS_ND + 1) * b.g.Cp;
+    const size_t wo = cell * Wcell + (size_t)id * b.g.Cp;
+    const int compact = b.g.Cp < b.g.ngridmax;
+    eg_ldsi *fstart = (eg_ldsi *)s_fstart, *fdims = (eg_ldsi *)s_fdims;
+    WalkJob job;
+    job.it = it, job.ist = ist;
+    job.ocap = b.g.Cp;
+    job.e13 = compact ? EGDST_E_CAPACITY : 13;
+    job.nthrhmax = b.g.nthrhmax;
+    job.stackcap = 2 * (TP_NF + 2);
+    job.fstart = fstart, job.dims = fdims;
+    job.cur = (eg_ldsi *)s_fcur, job.mark = (eg_ldsi *)s_fmark;
+    job.evfa0 = (const eg_ldsd *)s_evfa0;
+    job.stack = (eg_ldsi *)s_stack;
+    job.dbg = b.dbg + 16 * draw;
+    job.noseg = 1;
+    job.sh = sh;
+    job.segstat = b.segstat + 2 * (size_t)draw;
+    job.klog = nullptr, job.kcnt = nullptr, job.kcap = 0;
+    job.wM = job.wV = job.wC = nullptr, job.wcap = 0;
+    int classified = 0, hw_rows = 0, hw_th = 0;
+    unsigned long long evals = 0;
+    double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
+    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
+    if (stage == 0) {
+        job.npts = R->cnt + R->nfold;
+        job.nf = id + R->nfold + 1;
+        for (int f = tid; f < job.nf; f += WAVE) {
+            const int a = R->fstart[f], z = (f + 1 < job.nf) ? R->fstart[f + 1] : job.npts;
+            fstart[f] = (f < id) ? 0 : a;
+            fdims[f] = (f < id) ? 0 : z - a;
+        }
+        job.sec_id = id, job.sec_ev = R->evfa0;
+        job.cap = b.g.Cp;
+        job.og = b.pM + wo, job.ov = b.pV + wo, job.oc = b.pC + wo;
+        const size_t eto = (cell * MS_ND + id) * (size_t)b.g.nthrhmax;
+        job.oth = b.eTH + eto, job.oix = b.eIX + eto;
+        classified = R->fused;
+    } else {
+        int nall = 0;
+        for (int k = 0; k < MS_ND; k++) {
+            const TpRec *Rk = R + k;
+            if (tid == 0) s_fstart[k] = nall, s_fdims[k] = Rk->cnt, s_evfa0[k] = Rk->evfa0;
+            nall += Rk->cnt;
+            evals += Rk->evals;
+        }
+        job.npts = b.tpcell[cell].npts;
+        if (job.npts != nall) TP_DEFER_LISTED();  // (never expected: the sort packed exactly these lists)
+        job.nf = MS_ND;
+        job.sec_id = -1, job.sec_ev = 0;
+        job.cap = (int)Wcell;
+        job.og = oM + 1, job.ov = oV + 1, job.oc = oC + 1, job.oth = oTH, job.oix = oD;
+        classified = b.tpcell[cell].fused;
+        // rows of this cell that may hold leftovers of an earlier period or solve (see k_envelope); until the cell is complete
+        // the marks say "unknown", so that k_envelope, should the cell still be deferred, clears everything past its own end
+        hw_rows = b.thw[tk], hw_th = b.thhw[tk];
+        __syncthreads();  // (every lane has read the marks)
+        if (tid == 0) b.thw[tk] = b.g.Sp, b.thhw[tk] = b.g.nthrhmax;
+    }
+    __syncthreads();
+    int we = 0, wn = 0, wm = 0;
+    run_walk<false, false>(&E, job, b.qM + wo, b.qC + wo, b.qV + wo, b.qF + wo, b.rank + wo, b.gcls + wo, &we, &wn, &wm, classified);
+    if (stage == 0) {
+        if (we || wn >= b.g.ngridmax) TP_DEFER();  // (:884)
+        if (tid == 0) R->cnt = wn;
+        return;
+    }
+    if (we || wn == 0) TP_DEFER_LISTED();  // (wn == 0: error 16 of k_envelope)
+    const int outn = wn, outm = wm;
+    for (int i = outn + 1 + tid; i < hw_rows; i += WAVE) oM[i] = oC[i] = oV[i] = 0.0;
+    for (int i = outm + tid; i < hw_th; i += WAVE) oTH[i] = oD[i] = 0.0;
+    // ---- row 0 and lengths (saveoutput :917-952; evf(a0) :730) ------------------------------------
+    if (tid == 0) {
+        b.thw[tk] = outn + 1;
+        b.thhw[tk] = outm;
+        oM[0] = b.g.a0;
+        oC[0] = 0;
+        oV[0] = s_evfa0[(int)oD[0]];
+        b.tlen[tk] = outn + 1;
+        b.tthlen[tk] = outm;
+        if (evals) atomicAdd(&b.evals[draw], evals);
+        atomicAdd(&b.tpstat[2 * draw], 1u);
+        unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull * (unsigned long long)outm;  // (see k_envelope)
+        const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+        const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
+        by += 24ull * (unsigned long long)b.tlen[k1] + 16ull * (unsigned long long)b.tthlen[k1];
+        atomicAdd(&b.algbytes[draw], by);
+    }
+}
+#endif  // MS_ND > 1
+
 // ---------------------------------------------------------------------------------------------
 // Single-choice models (MS_ND == 1, e.g. the Deaton family): in the regular case the "envelope" of a cell is the stop
 // rule, the keep rule and the removal of repeated grid values -- a stream compaction with nothing sequential in it,
@@ -2860,7 +3280,7 @@ struct Env1Scratch {  // per schedule slot and state, zeroed by the host before 
     unsigned long long evals;
 };
 #define E1_IRREGULAR 1
-static __device__ __forceinline__ bool e1_kept(const Batch &b, const ProbeOut &P, size_t co, int n, int terminal)
+static __device__ __forceinline__ bool e1_kept(BatchRef b, const ProbeOut &P, size_t co, int n, int terminal)
 {
     if (terminal) return true;
     if (n == 0) return P.np != 0;
@@ -2873,15 +3293,16 @@ static __device__ __forceinline__ void e1_range(int nreq, int blk, int nb, int *
     *lo = blk * per;
     *hi = min(nreq + 1, *lo + per);
 }
-static __device__ __forceinline__ int e1_nreq(const Batch &b, const ProbeOut &P, int first, int terminal)
+static __device__ __forceinline__ int e1_nreq(BatchRef b, const ProbeOut &P, int first, int terminal)
 {
     if (terminal) return b.g.ngridm - 1;
     const int navail = P.grid ? min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls) : 0;
     return min(first, navail);
 }
 
-__global__ void __launch_bounds__(E1_BS) k_env1_a(Batch b, int it, int terminal, int *e1first, int nb)
+__global__ void __launch_bounds__(E1_BS) k_env1_a(const Batch *bp_, int it, int terminal, int *e1first, int nb)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
     int *F = e1first + ((size_t)b.draw0 * MS_NST + cellslot);
     if (b.status[draw] || terminal) return;
@@ -2902,7 +3323,7 @@ __global__ void __launch_bounds__(E1_BS) k_env1_a(Batch b, int it, int terminal,
 }
 
 // rows written by candidates [lo, hi) of a cell: kept, and not a repeat of the previous kept grid value; flags folds etc.
-static __device__ __forceinline__ int e1_count(const Batch &b, const ProbeOut &P, size_t co, int lo, int hi, int terminal, int *flags,
+static __device__ __forceinline__ int e1_count(BatchRef b, const ProbeOut &P, size_t co, int lo, int hi, int terminal, int *flags,
                                                int *n2, unsigned long long *ev, int write, double *oM, double *oC, double *oV, int d0)
 {
     // every thread takes a contiguous chunk; the predecessor of its first kept point is found by scanning back
@@ -2961,9 +3382,10 @@ static __device__ __forceinline__ int e1_scan(int v, int *sh, int *total)
     return ex;
 }
 
-__global__ void __launch_bounds__(E1_BS) k_env1_b(Batch b, int it, int terminal, Env1Scratch *sc, const int *e1first, int *blkcnt, int nb,
+__global__ void __launch_bounds__(E1_BS) k_env1_b(const Batch *bp_, int it, int terminal, Env1Scratch *sc, const int *e1first, int *blkcnt, int nb,
                                                   int defer_all /* tests: treat every cell as irregular */)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     __shared__ int sh[E1_BS];
     const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
     const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
@@ -2993,8 +3415,9 @@ __global__ void __launch_bounds__(E1_BS) k_env1_b(Batch b, int it, int terminal,
     if (ev) atomicAdd(&S->evals, ev);
 }
 
-__global__ void __launch_bounds__(E1_BS) k_env1_c(Batch b, int it, int terminal, Env1Scratch *sc, const int *e1first, const int *blkcnt, int nb)
+__global__ void __launch_bounds__(E1_BS) k_env1_c(const Batch *bp_, int it, int terminal, Env1Scratch *sc, const int *e1first, const int *blkcnt, int nb)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     __shared__ int sh[E1_BS];
     const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
     const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
@@ -3066,8 +3489,9 @@ __global__ void __launch_bounds__(E1_BS) k_env1_c(Batch b, int it, int terminal,
 }
 
 // the high-water marks of the cells the fast path completed (after k_env1_c: every workgroup has read the old marks)
-__global__ void k_env1_d(Batch b, int it, int ncells)
+__global__ void k_env1_d(const Batch *bp_, int it, int ncells)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncells) return;
     const int ist = k % MS_NST, draw = b.order[b.draw0 + k / MS_NST];
@@ -3102,8 +3526,9 @@ static __host__ __device__ __forceinline__ double eg_uniform(unsigned long long 
     return (double)(z >> 11) * 0x1p-53;
 }
 
-__global__ void __launch_bounds__(GRID_BS) k_simulate(Batch b, SimArgs a)
+__global__ void __launch_bounds__(GRID_BS) k_simulate(const Batch *bp_, SimArgs a)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int isim = blockIdx.x * GRID_BS + threadIdx.x;
     if (isim >= a.nsim) return;
     const int nt = b.g.nt, draw = a.draw + (int)blockIdx.y;
@@ -3292,8 +3717,9 @@ struct CallArgs {
     double *res;         // [narg]
 };
 
-__global__ void __launch_bounds__(GRID_BS) k_call(Batch b, CallArgs a)
+__global__ void __launch_bounds__(GRID_BS) k_call(const Batch *bp_, CallArgs a)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int i = blockIdx.x * GRID_BS + threadIdx.x;
     if (i >= a.narg) return;
     if (i >= a.first_bad) {
@@ -3426,16 +3852,20 @@ __global__ void k_moment_objective(const double *means, const int *counts, int n
     obj[d] = acc;
 }
 
-__global__ void k_fill_nan(double *p, size_t n, size_t per_draw)
+// zero_first: the gateway's NaN fill starts at element 1 of its output array (egdst_simulator.c:105: element 0 is written by
+// agent 0 anyway, or stays 0.0); the batched estimation step (egdst_simulate_batch_moments) promises NaN moments for a draw
+// that failed or whose agent 0 has no value, so there every element is NaN
+__global__ void k_fill_nan(double *p, size_t n, size_t per_draw, int zero_first)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (i % per_draw == 0) ? 0.0 : NAN;  // NaN fill starts at element 1 of a draw's output (egdst_simulator.c:105)
+    if (i < n) p[i] = (zero_first && i % per_draw == 0) ? 0.0 : NAN;
 }
 
 // Per-draw objective contribution for an estimation loop (new surface): the value and the
 // consumption at the first endogenous grid point of (it=0, ist=0); NaN when the draw failed.
-__global__ void k_objective(Batch b, double *out)
+__global__ void k_objective(const Batch *bp_, double *out)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     const int draw = blockIdx.x * blockDim.x + threadIdx.x;
     if (draw >= b.g.ndraw) return;
     const int slot = (b.g.nslots == 2) ? 0 : 0;
@@ -3446,12 +3876,15 @@ __global__ void k_objective(Batch b, double *out)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Checksum of every cell of one draw: the wrapping 64-bit sums of the bit patterns of the M, C, V rows (0..len-1) and
-// of the TH, D entries (0..thlen-1); out[(it*MS_NST+ist)*5 + {0..4}].  Equal sums <=> bit-identical tables (up to 2^-64
-// luck), so a full-size solution is compared with a committed fixture without moving gigabytes (tests/golden/big_*.npz).
+// Checksum of every cell of one draw: the wrapping 64-bit sums over the M, C, V rows i = 0..len-1 and over the TH, D
+// entries i = 0..thlen-1 of  bits(x_i) * (2 i + 1);  out[(it*MS_NST+ist)*5 + {0..4}].  The odd weight ties every value to
+// its row: swapped or shifted rows change the sum, which a plain sum of bit patterns would not notice.  Equal sums <=>
+// bit-identical tables (up to 2^-64 luck), so a full-size solution is compared with a committed fixture without moving
+// gigabytes (tests/golden/big_*.npz; tests/golden/make_golden_big.py: cell_sums is the same formula in numpy).
 #define CHK_BS 256
-__global__ void __launch_bounds__(CHK_BS) k_checksum(Batch b, int draw, unsigned long long *out)
+__global__ void __launch_bounds__(CHK_BS) k_checksum(const Batch *bp_, int draw, unsigned long long *out)
 {
+    BatchRef b = EG_BATCH_REF(bp_);
     __shared__ unsigned long long sh[CHK_BS];
     const int it = blockIdx.x / MS_NST, ist = blockIdx.x % MS_NST, tid = threadIdx.x;
     const Tab t = eg_tab(b, it, draw, ist);  // (history kept: slot = period)
@@ -3459,7 +3892,7 @@ __global__ void __launch_bounds__(CHK_BS) k_checksum(Batch b, int draw, unsigned
     for (int c = 0; c < 5; c++) {
         const int n = c < 3 ? t.len : t.thlen;
         unsigned long long acc = 0;
-        for (int i = tid; i < n; i += CHK_BS) acc += egm_bits(cols[c][i]);
+        for (int i = tid; i < n; i += CHK_BS) acc += egm_bits(cols[c][i]) * (2ull * (unsigned long long)i + 1ull);
         sh[tid] = acc;
         __syncthreads();
         for (int o = CHK_BS / 2; o > 0; o >>= 1) {

@@ -607,6 +607,7 @@ class egdstmodel:  # noqa: N801  (reference class name)
         self.dbgout = getattr(sol, 'dbgout', None)
         self._solution = sol
         self.M, self.D = sol.cells()
+        self.__dict__['_solver_cells'] = (id(self.M), id(self.D))  # the live handle holds exactly these cells (runtime.py)
         return sol
 
     def sim(self, *args):

@@ -33,7 +33,8 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_get_profile', 'egdst_objective_dev', 'egdst_get_objective', 'egdst_get_params',
                'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_get_regenerations', 'egdst_call', 'egdst_simulate_moments',
                'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited', 'egdst_simulate_batch_moments',
-               'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout', 'egdst_get_walk_stats']
+               'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout', 'egdst_get_walk_stats',
+               'egdst_set_cell_M', 'egdst_set_cell_D', 'egdst_set_solution', 'egdst_get_tp_stats']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -92,6 +93,10 @@ class ModelLibrary:
         L.egdst_get_cell_M.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.egdst_get_cell_D.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.egdst_get_solution.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + \
+            [C.POINTER(C.c_double)] * 5
+        L.egdst_set_cell_M.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_set_cell_D.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.egdst_set_solution.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + \
             [C.POINTER(C.c_double)] * 5
         L.egdst_simulate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
                                      C.c_longlong, C.c_int, C.POINTER(C.c_double)]
@@ -215,6 +220,12 @@ class Solver:
         """[ndraw, 2]: envelope walks cut into segments and merged / fallen back to one wave (egdst_get_walk_stats)"""
         out = np.zeros((self.ndraw, 2), dtype=np.uint32)
         self.lib.check(self.lib.lib.egdst_get_walk_stats(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def tp_stats(self):
+        """[ndraw, 2]: cells of the last solve completed by the throughput path of the envelope step / left to k_envelope"""
+        out = np.zeros((self.ndraw, 2), dtype=np.uint32)
+        self.lib.check(self.lib.lib.egdst_get_tp_stats(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def work(self):
@@ -341,6 +352,32 @@ class Solver:
         sol.nevals = int(self.evals()[1][draw])
         return sol
 
+    def set_solution(self, sol, draw=0):
+        """Import a host solution (the arrays `solution()` returns) into `draw`: egdst_set_solution, the inverse of the
+        export.  The handle then simulates / evaluates `call` from it without having solved (egdst_simulator.c:61-68)."""
+        ln = np.ascontiguousarray(sol.len, dtype=np.int32)
+        th = np.ascontiguousarray(sol.thlen, dtype=np.int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (sol.M, sol.C, sol.V, sol.D, sol.TH)]
+        d = self.desc
+        if arrs[0].shape != (self.nt, self.lib.info.nst, d['ngridmax'] + 1) or arrs[3].shape != (self.nt, self.lib.info.nst, d['nthrhmax']):
+            raise EgdstRuntimeError(1, 'set_solution: the arrays do not have the shapes of this handle')
+        self.lib.check(self.lib.lib.egdst_set_solution(self.h, draw, _ip(ln), _ip(th), *[_dp(a) for a in arrs]))
+
+    def set_cells(self, M, D, draw=0):
+        """Import the MATLAB-style cell arrays (nst x nt nested lists of (len x 4) [M C A V] and (thlen x 2) [D TH]
+        matrices, None / empty = unsolved cell) cell by cell: egdst_set_cell_M / egdst_set_cell_D, what a MEX shim of the
+        simulator gateway does with mxGetCell (shims/egdst_simulator_hip.c)."""
+        for ist in range(self.lib.info.nst):
+            for it in range(self.nt):
+                m = None if M[ist][it] is None else np.asfortranarray(np.asarray(M[ist][it], dtype=np.float64))
+                dd = None if D[ist][it] is None else np.asfortranarray(np.asarray(D[ist][it], dtype=np.float64))
+                nm = 0 if m is None or m.size == 0 else m.shape[0]
+                nd_ = 0 if dd is None or dd.size == 0 else dd.shape[0]
+                if nm and m.shape[1] != 4 or nd_ and dd.shape[1] != 2:
+                    raise EgdstRuntimeError(1, 'set_cells: cell (%d, %d) is not (len x 4) / (thlen x 2)' % (ist, it))
+                self.lib.check(self.lib.lib.egdst_set_cell_M(self.h, draw, it, ist, nm, _dp(m) if nm else None))
+                self.lib.check(self.lib.lib.egdst_set_cell_D(self.h, draw, it, ist, nd_, _dp(dd) if nd_ else None))
+
     def set_dbgout(self, on=True):
         """keep the kink log of the next solves (third output of the solver gateway)"""
         self.lib.check(self.lib.lib.egdst_set_dbgout(self.h, int(bool(on))))
@@ -379,9 +416,10 @@ class Solver:
         self.lib.check(self.lib.lib.egdst_set_profile(self.h, int(on)))
 
     def profile(self):
-        """(ms[3], launches[3], algorithmic bytes) of the last solve: kernels probe/terminal, grid, envelope."""
-        ms = np.zeros(3)
-        ln = np.zeros(3, dtype=np.int32)
+        """(ms[4], launches[4], algorithmic bytes) of the last solve: probe/terminal, the grid kernel, the envelope step,
+        regeneration (k_fixup_scan + k_fixup)."""
+        ms = np.zeros(4)
+        ln = np.zeros(4, dtype=np.int32)
         ab = C.c_longlong(0)
         self.lib.check(self.lib.lib.egdst_get_profile(self.h, _dp(ms), _ip(ln), C.byref(ab)))
         return ms, ln, int(ab.value)
@@ -502,15 +540,30 @@ def solve_model(model, dbgout=False):
     return sol
 
 
-def call_model(model, sw, args):
-    s = model.__dict__.get('_solver')
-    if s is None:
+def _solver_with_solution(model):
+    """The handle that serves `sim` and `call`.  The reference's gateways take the solution from the model object on every
+    call (egdst_simulator.c:61-68, egdst_call.c:28-34), not from the solve that produced it: when the handle of the last
+    `solve` still holds exactly model.M / model.D it is reused (nothing to upload), otherwise -- the cells were assigned,
+    e.g. restored from a saved model -- a fresh handle imports them (egdst_set_cell_M / egdst_set_cell_D)."""
+    if model.M is None or model.D is None:
         raise EgdstRuntimeError(40, 'Error: the model has not yet been solved!')
-    return s.call(sw, args, draw=0)
+    s = model.__dict__.get('_solver')
+    if s is not None and model.__dict__.get('_solver_cells') == (id(model.M), id(model.D)):
+        s.set_params(model.param_vector())   # loadparameters() of the gateways: the CURRENT values (after a setparam too)
+        return s
+    if s is not None:
+        s.close()
+    s = Solver(model._lib, model.descriptor(), ndraw=1, keep_history=True)
+    s.set_params(model.param_vector())   # (loadparameters() of the gateways: the CURRENT parameter values)
+    s.set_cells(model.M, model.D, draw=0)
+    model.__dict__['_solver'] = s
+    model.__dict__['_solver_cells'] = (id(model.M), id(model.D))
+    return s
+
+
+def call_model(model, sw, args):
+    return _solver_with_solution(model).call(sw, args, draw=0)
 
 
 def simulate_model(model, rndtype):
-    s = model.__dict__.get('_solver')
-    if s is None:
-        raise EgdstRuntimeError(40, 'Error: the model has not yet been solved!')
-    return s.simulate(model.init, model.randstream, rndtype, draw=0)
+    return _solver_with_solution(model).simulate(model.init, model.randstream, rndtype, draw=0)

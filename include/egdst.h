@@ -147,6 +147,20 @@ int egdst_get_cell_D(egdst_handle *h, int draw, int it, int ist, double *out /* 
 int egdst_get_solution(egdst_handle *h, int draw, int *lens, int *thlens, double *M, double *C, double *V,
                        double *D, double *TH);
 
+/* Solution import, the inverse of the export calls.  The reference's simulator and accessor gateways read the cell arrays
+ * M and D from the model object on every call (egdst_simulator.c:61-68, egdst_call.c:28-34; the class is ConstructOnLoad,
+ * egdstmodel.m:1, so a saved model is simulated without solving again): a handle that never ran egdst_solve is given the
+ * cells here and then serves egdst_simulate*, egdst_call, egdst_get_cell_* and egdst_get_checksums exactly as the handle
+ * that solved them.  Same layouts as the export: M cell (len x 4) column-major [M C A V] (A is ignored, it is M - C),
+ * D cell (thlen x 2) [D TH]; len == 0 marks the cell unsolved (the reference's empty cell).  Rows past len are zeroed.
+ * Requires keep_history=1 and egdst_set_params for the draw (the model functions read the parameters).  The draw's
+ * status becomes 0.  EGDST_E_ARG if a cell exceeds ngridmax+1 rows or nthrhmax thresholds. */
+int egdst_set_cell_M(egdst_handle *h, int draw, int it, int ist, int len, const double *in /* [len*4] */);
+int egdst_set_cell_D(egdst_handle *h, int draw, int it, int ist, int thlen, const double *in /* [thlen*2] */);
+/* Bulk import of one draw, argument for argument the arrays egdst_get_solution fills (none may be NULL). */
+int egdst_set_solution(egdst_handle *h, int draw, const int *lens, const int *thlens, const double *M, const double *C,
+                       const double *V, const double *D, const double *TH);
+
 /* Forward simulation of draw `draw` (egdst_simulator.c:47-117): init [nsim x 2] column-major (state index
  * base-1, cash-in-hand), randstream uniforms, rndtype 1 = every agent reuses the head of the stream.
  * sims: [nsimout x nt x nsim] column-major, nsimout = 11+nnst+nnd+neq, NaN where the agent is dead. */
@@ -190,12 +204,14 @@ int egdst_call(egdst_handle *h, int draw, int sw, int narg, int ncol, const doub
 int egdst_objective_dev(egdst_handle *h, double *out_dev);
 int egdst_get_objective(egdst_handle *h, double *out /* host, [2*ndraw] */);
 
-/* Measurement: with profiling on, every kernel launch of a solve is bracketed by HIP events on
- * the handle's stream.  egdst_get_profile returns, for {0: probe/terminal, 1: grid, 2: envelope}, the summed
- * device time in ms and the number of launches of the LAST solve, and the algorithmic table bytes of that solve
- * summed over draws (24 B per table row read once per period, 24 B per row written, 16 B per threshold). */
+/* Measurement: with profiling on, the launches of a solve are bracketed by HIP events on the stream they are
+ * launched on (the draw groups' streams).  egdst_get_profile returns, for the classes {0: k_probe / k_terminal, 1: the grid
+ * kernel (k_grid_lds, k_grid_wide or k_grid) alone, 2: the envelope step (k_envelope, or the kernels of its throughput path),
+ * 3: regeneration of guess streams (k_fixup_scan + k_fixup)}, the summed device time in ms and the number of bracketed launches
+ * of the LAST solve, and the algorithmic table bytes of that solve summed over draws (24 B per table row read once per
+ * period, 24 B per row written, 16 B per threshold). */
 int egdst_set_profile(egdst_handle *h, int on);
-int egdst_get_profile(egdst_handle *h, double *ms /* [3] */, int *launches /* [3] */, long long *algbytes);
+int egdst_get_profile(egdst_handle *h, double *ms /* [4] */, int *launches /* [4] */, long long *algbytes);
 
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);
@@ -210,9 +226,10 @@ int egdst_get_debug(egdst_handle *h, int draw, int *out16);
 int egdst_set_dbgout(egdst_handle *h, int on);
 int egdst_get_dbgout(egdst_handle *h, int draw, double *out /* [nt*nst*nd*2*nt * 7] */, int *nrows);
 
-/* Checksums of one draw's solution, computed on the device: out[(it*nst+ist)*5 + k] = wrapping 64-bit sum of the bit
- * patterns of column k in {M, C, V} over the cell's rows and of {TH, D} over its thresholds.  Lets a caller (and the
- * parity tests at BASELINE.json's full sizes) compare whole solutions without exporting them.  Requires keep_history=1. */
+/* Checksums of one draw's solution, computed on the device: out[(it*nst+ist)*5 + k] = wrapping 64-bit sum over the rows i of
+ * bits(x_i) * (2 i + 1) for column k in {M, C, V} of the cell's rows and {TH, D} of its thresholds (the odd weight pins the
+ * order of the rows).  Lets a caller (and the parity tests at BASELINE.json's full sizes) compare whole solutions without
+ * exporting them.  Requires keep_history=1. */
 int egdst_get_checksums(egdst_handle *h, int draw, unsigned long long *out /* [nt*nst*5] */);
 
 /* Diagnostics: this library's device exp (fn 0), log (1), pow (2) on host arrays x, y (y only for pow), n values.
@@ -223,6 +240,12 @@ int egdst_math_eval(int fn, int n, const double *x, const double *y, double *out
  * out[2*draw+1] = walks whose segment predictions failed the check and were redone by one wave (results are the same
  * either way; environment EGDST_NOSEG=1 at create turns the cutting off). */
 int egdst_get_walk_stats(egdst_handle *h, unsigned *out /* [2*ndraw] */);
+
+/* Envelope step of the last solve per draw: out[2*draw] = (state, period) cells completed by the throughput path (five lean
+ * kernels with one wave per envelope walk, used for batches of >= 512 cells per period; environment EGDST_ENV_TP=0/1 at
+ * solve overrides), out[2*draw+1] = cells it left to the general kernel (an error condition, more than 64 monotone pieces
+ * in a choice list, a failed draw, an infeasible state).  Results are the same either way. */
+int egdst_get_tp_stats(egdst_handle *h, unsigned *out /* [2*ndraw] */);
 
 /* Raw device views for callers that keep data resident (bench, estimation loops). */
 int egdst_device_tables(egdst_handle *h, int it, const double **M_dev, const double **C_dev, const double **V_dev,

@@ -147,6 +147,8 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { retu
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)malloc(n ? n : 1); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void *p) { free(p); return 0; }
+static inline hipError_t hipHostMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }
+static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, int)
 {

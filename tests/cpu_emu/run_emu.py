@@ -38,4 +38,4 @@ if __name__ == '__main__':
                                 bool(int(os.environ.get('EMU_PAR_BLOCKS', '0'))), int(os.environ.get('EMU_WAVE', '1')))
     print(name, 'ok=%s status=%d where=%s rows=%d/%d evals=%d/%d max_rel=%.2e max_dth=%.2e %s' % (
         ok, sol.status, sol.where, sol.total_rows(), ref.total_rows(), sol.nevals, ref.nevals, rep['max_rel'],
-        rep['max_dth'], rep['problems'][:3]), 'geometry', s.geometry(), 'capacity_retries', s.capacity_retries, 'deferrals', int(s.debug(0)[15]), 'walks segmented/fallback', s.walk_stats()[0].tolist())
+        rep['max_dth'], rep['problems'][:3]), 'geometry', s.geometry(), 'capacity_retries', s.capacity_retries, 'deferrals', int(s.debug(0)[15]), 'walks segmented/fallback', s.walk_stats()[0].tolist(), 'tp done/left', s.tp_stats()[0].tolist())

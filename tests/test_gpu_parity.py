@@ -250,6 +250,79 @@ def test_history_based_schedule_does_not_change_results():
     assert np.array_equal(s.status()[0], first[0]) and np.array_equal(s.evals()[1], first[1])
 
 
+TP_CASES = {
+    'retirement2': lambda: examples.retirement2(),
+    'C2': lambda: workloads.c2()[0],
+    'C2_a0neg_T60': lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10),
+    'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
+    'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5),
+    'model2': lambda: examples.model2(),
+    'retirement_hc': lambda: examples.retirement_hc(),
+    'three_points_per_choice': lambda: examples.retirement2(T=3, ngridm=3, ngridmax=40),
+    'ngridmax_just_above_ngridm': lambda: examples.occ3(T=6, ngridm=30, ngridmax=31),
+}
+
+
+@pytest.mark.parametrize('name', sorted(TP_CASES))
+@pytest.mark.parametrize('keys', ['lds_keys', 'sampled_keys'])
+def test_throughput_envelope_path_bit_exact(name, keys, monkeypatch):
+    """The envelope step of big batches runs as five lean kernels with one wave per walk (k_tp_prep / k_tp_sort / k_tp_walk,
+    egdst_kernels.hip) and hands the cells it does not take to k_envelope.  Forced on here for single solves (EGDST_ENV_TP=1):
+    tables, thresholds and evaluation counts equal the oracle's bit for bit, with the sort's M keys whole in LDS and with so
+    little LDS that it works on a sampled index of them; and the path really does the cells (egdst_get_tp_stats)."""
+    monkeypatch.setenv('EGDST_ENV_TP', '1')
+    if keys == 'sampled_keys':
+        monkeypatch.setenv('EGDST_TP_LKCAP', '96')
+    m = TP_CASES[name]()
+    s = gpu_solve(m)
+    sol = s.solution(0)
+    ref = Oracle(m).solve()
+    assert (sol.status == 0) == (ref.rc == 0)
+    ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+    assert ok and sol.nevals == ref.nevals, (name, rep)
+    done, left = s.tp_stats()[0]
+    feasible_cells = int((sol.len[:-1] > 0).sum())          # (the terminal period is k_envelope's)
+    assert done + left == s.lib.info.nst * (s.nt - 1)       # every cell of every other period went through the path's last stage once
+    if name not in ('ngridmax_just_above_ngridm',):
+        assert done >= 0.9 * feasible_cells, (done, left, feasible_cells)
+    s.close()
+
+
+def test_throughput_envelope_path_in_a_batch_with_failing_draws(monkeypatch):
+    """600 draws of C2 at ngridm=300, T=30 (>= 512 cells per period: the throughput path is the default) and the same draws
+    through k_envelope alone (EGDST_ENV_TP=0): status, failing period, evaluation counts, objective and -- for every draw
+    -- the checksums of all cells are identical; a sample of the draws equals the oracle's tables bit for bit, and the
+    draws on which the reference algorithm breaks down fail with the oracle's message."""
+    m, gen = workloads.c2(ngridm=300, T=30)
+    P = gen(600)
+    lib = build.build_model(m)
+    res = {}
+    for tp in ('default', '0'):
+        if tp == '0':
+            monkeypatch.setenv('EGDST_ENV_TP', '0')
+        s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=True)
+        s.set_params(P)
+        s.solve(raise_on_error=False)
+        res[tp] = (s.status(), s.evals()[1], s.objective(), [s.checksums(i) for i in range(0, len(P), 7)], s.tp_stats())
+        if tp == 'default':
+            orc = Oracle(m)
+            st = s.status()[0]
+            for i in list(range(0, 40)) + [int(k) for k in np.nonzero(st)[0][:5]]:
+                ref = orc.solve(P[i])
+                assert (st[i] == 0) == (ref.rc == 0), i
+                if ref.rc:
+                    assert s.lib.lib.egdst_strerror(int(st[i])).decode().strip() == ref.err.strip()
+                else:
+                    ok, rep = compare(s.solution(i), ref, 0.0, 0.0)
+                    assert ok and s.evals()[1][i] == ref.nevals, (i, rep)
+        s.close()
+    a, b_ = res['default'], res['0']
+    assert np.array_equal(a[0][0], b_[0][0]) and np.array_equal(a[0][1], b_[0][1])
+    assert np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2], equal_nan=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b_[3]))
+    assert a[4][:, 0].sum() > 0.95 * (a[4].sum()) and b_[4].sum() == 0      # the path did the cells / was off
+
+
 EDGE = {
     'single_period_T_equals_t0': lambda: examples.deaton2(T=1, t0=1),
     'two_periods_8_points': lambda: examples.retirement2(T=2, ngridm=8),
@@ -309,6 +382,104 @@ def test_class_surface_call():
     from egdst_amd import EgdstError
     with pytest.raises(EgdstError):
         m.call('nonsense', args)
+
+
+@pytest.mark.parametrize('name', ['retirement2', 'retire8', 'retirement_hc'])
+@pytest.mark.parametrize('how', ['cells', 'bulk'])
+def test_import_solution_then_simulate_and_call_without_solving(name, how):
+    """Row (b) of SURVEY section 8: the reference's simulator and accessor gateways take M and D from the model object
+    (egdst_simulator.c:61-68, egdst_call.c:28-34), not from a solve in the same process.  A handle that NEVER solved is given
+    the exported cells (egdst_set_cell_M / _D, the calls shims/egdst_simulator_hip.c makes; or egdst_set_solution) and must
+    then return the simulated paths, every accessor value, the cell export and the checksums of the handle that solved."""
+    from call_cases import call_cases
+    m = {'retirement2': lambda: examples.retirement2(), 'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5),
+         'retirement_hc': lambda: examples.retirement_hc()}[name]()
+    s = gpu_solve(m)
+    sol = s.solution(0)
+    assert sol.status == 0
+    f = runtime.Solver(s.lib, m.descriptor(), ndraw=1, keep_history=True)
+    with pytest.raises(runtime.EgdstRuntimeError):
+        f.simulate(np.array([[1, 1.0]]), np.random.default_rng(0).random(4 * s.nt))   # not solved, nothing imported
+    f.set_params(m.param_vector())
+    if how == 'cells':
+        M, D = sol.cells()
+        f.set_cells(M, D)
+    else:
+        f.set_solution(sol)
+    nst = s.lib.info.nst
+    rng = np.random.default_rng(11)
+    nsim = 64
+    feas = [ist for ist in range(nst) if sol.len[0, ist] > 0]
+    init = np.column_stack([rng.choice(feas, nsim) + 1.0, rng.uniform(m.a0, m.mmax, nsim)])
+    if name == 'retirement_hc':   # (initial states in the lower half of the continuous grid: see DESIGN.md section 8, N4)
+        init = np.column_stack([rng.integers(1, 4, nsim), rng.uniform(0.2, 9, nsim)])
+    rs = rng.random(4 * s.nt * nsim)
+    for rndtype in (0, 1):
+        a, b = s.simulate(init, rs, rndtype), f.simulate(init, rs, rndtype)
+        assert np.array_equal(a, b, equal_nan=True) and np.isfinite(a[:, 0, 0]).all()
+    for sw, args in call_cases(m, s.nt, nst, s.lib.info.nd):
+        assert np.array_equal(s.call(sw, args), f.call(sw, args), equal_nan=True), sw
+    assert np.array_equal(s.checksums(0), f.checksums(0))
+    for it in (0, s.nt // 2, s.nt - 1):
+        for ist in range(nst):
+            assert np.array_equal(s.cell_M(0, it, ist), f.cell_M(0, it, ist)) and np.array_equal(s.cell_D(0, it, ist), f.cell_D(0, it, ist))
+    # rows past a table's end are zero on the importing handle too (the reference reads one past a one-row table)
+    g = f.solution(0)
+    for it in range(s.nt):
+        for ist in range(nst):
+            assert not g.M[it, ist, g.len[it, ist]:].any() and not g.TH[it, ist, g.thlen[it, ist]:].any()
+    # importing over a solved handle replaces the solution of that draw (and a later solve replaces the import)
+    s2 = gpu_solve(m, params=m.param_vector() * 1.01)
+    s2.set_solution(sol)
+    assert np.array_equal(s2.checksums(0), s.checksums(0))
+    s2.solve()
+    assert not np.array_equal(s2.checksums(0), s.checksums(0))
+    for h in (s, f, s2):
+        h.close()
+
+
+def test_import_rejects_what_does_not_fit():
+    m = examples.retirement2()
+    s = gpu_solve(m)
+    f = runtime.Solver(s.lib, m.descriptor(), ndraw=1, keep_history=False)
+    with pytest.raises(runtime.EgdstRuntimeError):
+        f.set_solution(s.solution(0))   # needs keep_history=1
+    f.close()
+    f = runtime.Solver(s.lib, m.descriptor(), ndraw=1, keep_history=True)
+    big = np.zeros((m.ngridmax + 5, 4), order='F')
+    with pytest.raises(runtime.EgdstRuntimeError):
+        f.lib.check(f.lib.lib.egdst_set_cell_M(f.h, 0, 0, 0, big.shape[0], big.ctypes.data_as(runtime.C.POINTER(runtime.C.c_double))))
+    with pytest.raises(runtime.EgdstRuntimeError):
+        f.lib.check(f.lib.lib.egdst_set_cell_M(f.h, 0, s.nt, 0, 0, None))   # period out of range
+    f.close()
+    s.close()
+
+
+def test_class_surface_sim_and_call_from_assigned_cells():
+    """egdstmodel is ConstructOnLoad (egdstmodel.m:1): a model whose M / D were restored (assigned) simulates and answers
+    `call` without solving; and `sim` after `setparam` uses the NEW parameter values with the OLD solution, as the
+    reference's gateway does (loadparameters at every call, egdst_simulator.c:60)."""
+    m = examples.retirement2()
+    m.compile()
+    sol = m.solve()
+    init = np.array([[1, 0.25], [1, 3.0], [1, 8.0]])
+    m.randstream = np.random.default_rng(7).random(4 * m.nt * len(init))
+    sims = m.sim(init)
+    vf = m.call('vf', [[m.t0 + 3, 1, 2.5]])
+    m2 = examples.retirement2()
+    m2.compile()
+    m2.M, m2.D = sol.cells()        # e.g. read back from disk
+    m2.randstream = m.randstream
+    assert np.array_equal(m2.sim(init), sims, equal_nan=True)
+    assert np.array_equal(m2.call('vf', [[m.t0 + 3, 1, 2.5]]), vf)
+    ref = Oracle(m)
+    rsol = ref.solve()
+    m.setparam('wage', 1.2)         # new wage, old solution
+    refm = examples.retirement2()
+    refm.setparam('wage', 1.2)
+    expect = Oracle(refm).sim(rsol, init, m.randstream)
+    assert np.array_equal(m.sim(init), expect, equal_nan=True)
+    assert not np.array_equal(expect, sims, equal_nan=True)
 
 
 def test_simulated_moments_on_device():

@@ -83,6 +83,20 @@ def test_compact_capacity_overflow_is_redone_exactly():
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
 
 
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('args', [['retirement2', 'T=8, ngridm=60'], ['retirement8', 'T=5, ngridm=30, ny=3']])
+def test_solution_import_serves_simulator_and_accessor(args):
+    """egdst_set_cell_M/_D and egdst_set_solution (the inverse of the export: what the simulator and accessor gateways of
+    the reference read from the model object, egdst_simulator.c:61-68) on a handle that never solved: simulated paths
+    and accessor values equal the oracle's, tables and checksums equal the solving handle's, ASan clean."""
+    env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_import.py')] + args, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'import mismatches: 0' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
 def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
     """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=27): with ping-pong
     tables the failure must be the oracle's (error 15 at it=26), not a success built on stale rows."""
