@@ -15,25 +15,36 @@
 #endif
 
 // Address spaces are kept in the TYPES: the sorted stream is either LDS- or global-resident (template
-// parameter L), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
+// parameter L, see EgMem), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
 // avoided on purpose -- selecting between LDS- and global-derived generic pointers made hipcc's backend fail
 // ("Illegal instruction detected ... src_shared_base") on one model, and typed LDS accesses are ds_* ops anyway.
 // (EG_LDS_AS, eg_ldsd, eg_ldsi: typed LDS pointers, defined in egdst_device.h)
-template <bool L> struct EgMem {
+// L = 0: the stream in global memory;  1: in LDS;  2: in LDS except the consumption column, which the walk only copies to
+// its output rows (and reads at a kink) -- 24 B per point instead of 32, for the one-wave walks of the throughput path.
+template <int L> struct EgMem {
     typedef double D;
+    typedef double DC;  // the consumption column
     typedef int I;
     typedef int S;  // function ids and sorted positions
 };
-template <> struct EgMem<true> {
+template <> struct EgMem<1> {
     typedef eg_ldsd D;
+    typedef eg_ldsd DC;
     typedef eg_ldsi I;
     typedef eg_ldss S;  // 16 bits in LDS: 32 B per point instead of 36
 };
+template <> struct EgMem<2> {
+    typedef eg_ldsd D;
+    typedef double DC;
+    typedef eg_ldsi I;
+    typedef eg_ldss S;
+};
 
-template <bool L> struct EnvCtxT {
+template <int L> struct EnvCtxT {
     const ms_env *E;
     int it, ist, nf;
-    const typename EgMem<L>::D *m, *c, *v;  // sorted points
+    const typename EgMem<L>::D *m, *v;      // sorted points
+    const typename EgMem<L>::DC *c;
     const typename EgMem<L>::S *f;
     const typename EgMem<L>::S *rank;       // position lists
     const eg_ldsi *fstart;
@@ -61,7 +72,7 @@ template <bool L> struct EnvCtxT {
 };
 
 // one row of the solver gateway's third output (lane 0 of the walking wave calls this)
-template <bool L> static __device__ __forceinline__ void env_log_kink(EnvCtxT<L> &e, double x, double pol0, double pol1)
+template <int L> static __device__ __forceinline__ void env_log_kink(EnvCtxT<L> &e, double x, double pol0, double pol1)
 {
     if (!e.klog) return;
     const int n = *e.kcnt;
@@ -75,12 +86,12 @@ template <bool L> static __device__ __forceinline__ void env_log_kink(EnvCtxT<L>
     *e.kcnt = n + 1;
 }
 
-template <bool L> static __device__ __forceinline__ double env_evf(const EnvCtxT<L> &e, int f)
+template <int L> static __device__ __forceinline__ double env_evf(const EnvCtxT<L> &e, int f)
 {
     if (e.sec_id >= 0) return f == e.sec_id ? e.sec_ev : -INFINITY;
     return e.evfa0[f];
 }
-template <bool L> static __device__ __forceinline__ int env_at(EnvCtxT<L> &e, int f, int k)
+template <int L> static __device__ __forceinline__ int env_at(EnvCtxT<L> &e, int f, int k)
 {
     const int o = e.fstart[f] + k;
     if (o < 0 || o >= e.cap) {  // never expected; turns a wild access into an error code
@@ -105,18 +116,22 @@ template <bool L> static __device__ __forceinline__ int env_at(EnvCtxT<L> &e, in
 
 // value (which=0) or consumption (which=1) of f on the segment that starts at its k-th point; -inf outside
 // the segment: "No extrapolation allowed: this is essential for the correct envelop" (linter2, :1585-1593)
-template <bool L> static __device__ __forceinline__ double env_seg(EnvCtxT<L> &e, int f, int k, double x, int which)
+template <int L> static __device__ __forceinline__ double env_seg(EnvCtxT<L> &e, int f, int k, double x, int which)
 {
     int a = env_at(e, f, k), b = env_at(e, f, k + 1);
     double ga = e.m[a], gb = e.m[b];
-    double fa = which ? e.c[a] : e.v[a], fb = which ? e.c[b] : e.v[b];
+    double fa, fb;  // (two loads each way: the columns may live in different address spaces)
+    if (which)
+        fa = e.c[a], fb = e.c[b];
+    else
+        fa = e.v[a], fb = e.v[b];
     if (x == ga) return fa;
     if (x < ga) return -INFINITY;
     if (x > gb) return -INFINITY;
     return fb * (x - ga) / (gb - ga) + fa * (gb - x) / (gb - ga);
 }
 
-template <bool L> static __device__ __forceinline__ double env_analytic(const EnvCtxT<L> &e, int f, double x)
+template <int L> static __device__ __forceinline__ double env_analytic(const EnvCtxT<L> &e, int f, double x)
 {
     ms_pv cv;
     cv.it = e.it;
@@ -126,14 +141,14 @@ template <bool L> static __device__ __forceinline__ double env_analytic(const En
     return ms_utility(e.E, &cv, x - e.E->a0) + ms_discount(e.E, &cv) * env_evf(e, f);
 }
 
-template <bool L> static __device__ __forceinline__ double env_fn(EnvCtxT<L> &e, int f, double x)  // funcvalue, :1553-1567
+template <int L> static __device__ __forceinline__ double env_fn(EnvCtxT<L> &e, int f, double x)  // funcvalue, :1553-1567
 {
     if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 0);
     if (env_evf(e, f) == -INFINITY) return -INFINITY;
     return env_analytic(e, f, x);
 }
 
-template <bool L> static __device__ __forceinline__ double env_policy(EnvCtxT<L> &e, int f, double x)  // :1406-1408, :1859-1864
+template <int L> static __device__ __forceinline__ double env_policy(EnvCtxT<L> &e, int f, double x)  // :1406-1408, :1859-1864
 {
     if (e.cur[f] >= 0) return env_seg(e, f, e.cur[f], x, 1);
     if (env_evf(e, f) == -INFINITY) return EG_ZEROC;
@@ -143,7 +158,7 @@ template <bool L> static __device__ __forceinline__ double env_policy(EnvCtxT<L>
 static __device__ __forceinline__ double env_sgn(double x) { return x > 0 ? 1.0 : -1.0; }
 
 // brsolve (:1918-1968): bisection between an analytic value function `fa` and the segment (fl,kl)
-template <bool L> static __device__ __forceinline__ void env_bisect(EnvCtxT<L> &e, double *b0, double *b1, int fl, int kl, int fa)
+template <int L> static __device__ __forceinline__ void env_bisect(EnvCtxT<L> &e, double *b0, double *b1, int fl, int kl, int fa)
 {
     // The reference re-evaluates both bracket ends at every level of its recursion; they are pure functions of
     // the bracket, so the values are carried along instead (bit-identical, a third of the evaluations).
@@ -187,7 +202,7 @@ template <bool L> static __device__ __forceinline__ void env_bisect(EnvCtxT<L> &
 }
 
 // thresholds (:1596-1915)
-template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
+template <int L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
 {
     const double a0 = e.E->a0;
     int sp = 0;
@@ -303,11 +318,11 @@ template <bool L> static __device__ __forceinline__ void env_crossing(EnvCtxT<L>
     }
 }
 
-template <bool L> static __device__ __forceinline__ void env_reset_marks(EnvCtxT<L> &e)
+template <int L> static __device__ __forceinline__ void env_reset_marks(EnvCtxT<L> &e)
 {
     for (int l = 0; l < e.nf; l++) e.mark[l] = (e.dims[l] > 0 ? 0 : 1);
 }
-template <bool L> static __device__ __forceinline__ void env_push(EnvCtxT<L> &e, double g, double v, double c)
+template <int L> static __device__ __forceinline__ void env_push(EnvCtxT<L> &e, double g, double v, double c)
 {
     e.og[e.oi] = g;
     e.ov[e.oi] = v;
@@ -319,7 +334,7 @@ template <bool L> static __device__ __forceinline__ void env_push(EnvCtxT<L> &e,
 // ---- the merge walk (:1262-1550) ------------------------------------------------------------------------
 // env_begin: state before the first point; env_step: one iteration of the reference's while loop for the
 // sorted position i (returns false when the walk must stop).  dims[] must hold the points per function.
-template <bool L> static __device__ __forceinline__ void env_begin(EnvCtxT<L> &e)
+template <int L> static __device__ __forceinline__ void env_begin(EnvCtxT<L> &e)
 {
     for (int f = 0; f < e.nf; f++) e.cur[f] = -1;
     double bound = INFINITY;  // min over functions of the last grid point (:1266-1271)
@@ -335,7 +350,7 @@ template <bool L> static __device__ __forceinline__ void env_begin(EnvCtxT<L> &e
     e.pm = -1;
 }
 
-template <bool L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e, int i)
+template <int L> static __device__ __forceinline__ bool env_step(EnvCtxT<L> &e, int i)
 {
     const double a0 = e.E->a0, bound = e.bound;
     const int f = e.f[i];
@@ -497,7 +512,7 @@ static __device__ __forceinline__ int env_wave_min(int x, int nf)
 // Over the functions j with dims[j] > 0, j != ex1, j != ex2 (and, with marks, mark[j] != 1):
 //   first != 0: the smallest j with thr < value_j(x);   first == 0: the j of the largest value_j(x) > thr,
 //   smallest index among equals.  Returns j (or -1) and its value in *val.
-template <bool L>
+template <int L>
 static __device__ __forceinline__ int env_wave_pick(EnvCtxT<L> &e, double x, double thr, int ex1, int ex2, int marks, int first,
                                                     double *val)
 {
@@ -521,7 +536,7 @@ static __device__ __forceinline__ int env_wave_pick(EnvCtxT<L> &e, double x, dou
     return bj;
 }
 
-template <bool L> static __device__ __forceinline__ void env_crossing_wave(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
+template <int L> static __device__ __forceinline__ void env_crossing_wave(EnvCtxT<L> &e, int pri0, int nwi0, int mode)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
     const double a0 = e.E->a0;
@@ -631,7 +646,7 @@ template <bool L> static __device__ __forceinline__ void env_crossing_wave(EnvCt
     }
 }
 
-template <bool L> static __device__ __forceinline__ void env_push_wave(EnvCtxT<L> &e, double g, double v, double c, int lane)
+template <int L> static __device__ __forceinline__ void env_push_wave(EnvCtxT<L> &e, double g, double v, double c, int lane)
 {
     if (lane == 0) {
         e.og[e.oi] = g;
@@ -642,7 +657,7 @@ template <bool L> static __device__ __forceinline__ void env_push_wave(EnvCtxT<L
     e.lastg = g;
 }
 
-template <bool L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L> &e, int i)
+template <int L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L> &e, int i)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
     const double a0 = e.E->a0, bound = e.bound;
@@ -774,7 +789,7 @@ template <bool L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L
 
 #ifdef EGDST_SEQ_WALK
 // Plain sequential walk (diagnostic build only).
-template <bool L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e, int npts)
+template <int L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e, int npts)
 {
     env_begin(e);
     for (int i = 0; i < npts && e.m[i] <= e.bound && !e.err; i++)
@@ -793,7 +808,7 @@ template <bool L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e,
 // with ballot/popcount compaction in order, and the first irregular position is handed to env_step() with
 // cur[] rebuilt from the counts.  Every lane executes env_step redundantly (uniform control flow, identical
 // stores).  Output is identical to env_walk(); the CPU harness checks that bit for bit.
-template <bool L> static __device__ __forceinline__ int env_count_before(const EnvCtxT<L> &e, int j, int p)
+template <int L> static __device__ __forceinline__ int env_count_before(const EnvCtxT<L> &e, int j, int p)
 {
     // number of points of function j at sorted positions < p (the position list of j is ascending)
     const typename EgMem<L>::S *lst = e.rank + e.fstart[j];
@@ -808,7 +823,7 @@ template <bool L> static __device__ __forceinline__ int env_count_before(const E
     return lo;
 }
 
-template <bool L> static __device__ __forceinline__ double env_fn_at(EnvCtxT<L> &e, int j, int curj, double x)
+template <int L> static __device__ __forceinline__ double env_fn_at(EnvCtxT<L> &e, int j, int curj, double x)
 {
     if (curj >= 0) return env_seg(e, j, curj, x, 0);
     if (env_evf(e, j) == -INFINITY) return -INFINITY;
@@ -817,7 +832,7 @@ template <bool L> static __device__ __forceinline__ double env_fn_at(EnvCtxT<L> 
 
 // value of function j at x given that cj of its points precede the position (wave walk; no bounds guards: below the
 // bound every function still has a point ahead, so cj <= dims[j]-1)
-template <bool L> static __device__ __forceinline__ double env_fn_cnt(EnvCtxT<L> &e, int j, int cj, double x)
+template <int L> static __device__ __forceinline__ double env_fn_cnt(EnvCtxT<L> &e, int j, int cj, double x)
 {
     if (cj >= 1) {
         const int base = e.fstart[j] + cj - 1;
@@ -841,7 +856,7 @@ template <bool L> static __device__ __forceinline__ double env_fn_cnt(EnvCtxT<L>
 //   sign bit   always irregular (at/after the bound, inconsistent stream)
 #define ENV_CLS_FORCE ((int)0x80000000)
 #define ENV_CLS_NOMASK (1 << 30)
-template <bool L>
+template <int L>
 static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typename EgMem<L>::I *cls, int tid, int nthreads)
 {
     double bound = INFINITY;
@@ -879,7 +894,7 @@ static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typ
 // state.  later == 1: a later segment (run_walk): starts in the regular phase with the current max function pm0 and the
 // last output grid value lastg0 that the preceding segment is PREDICTED to end with; rows and thresholds are counted
 // from 0 in this segment's own output region.  On return e.pm / e.lastg hold the state after position p1-1.
-template <bool L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, int p0 = 0, int p1 = -1, int later = 0,
+template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, int p0 = 0, int p1 = -1, int later = 0,
                                                                        int pm0 = -1, double lastg0 = 0)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);

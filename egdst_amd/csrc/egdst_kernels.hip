@@ -52,8 +52,10 @@
 #if defined(__SANITIZE_ADDRESS__)
 #include <sanitizer/asan_interface.h>
 #define EG_EMU_POISON(p, n) __asan_poison_memory_region((const void *)(p), (n))
+#define EG_EMU_UNPOISON_DYN(p) __asan_unpoison_memory_region((const void *)(p), sizeof(double) * (20480 + 64))  // (a phase of a fused kernel lays the LDS out anew)
 #else
 #define EG_EMU_POISON(p, n) ((void)0)
+#define EG_EMU_UNPOISON_DYN(p) ((void)0)
 #endif
 #else
 #define EG_DYN_LDS(name) extern __shared__ double name[]
@@ -169,8 +171,11 @@ struct LaneEval {
     double bshock, bcash;
 };
 
+// lt: nullptr, or (models with one state) the next-period table staged in LDS by the caller -- k_fixup's speculative batches:
+// their bracket searches were 2 x 11 dependent L2 round trips per term and made a regeneration ~0.8 ms (profiles/r03_*)
+template <class TT = Tab>
 static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env *E, const ms_pv *cur, int slot1, int draw,
-                                                        double A)
+                                                        double A, const TT *lt = nullptr)
 {
     LaneEval r;
     const int ny = b.g.ny;
@@ -192,7 +197,14 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env
             if (pr1pre == 0.0) continue;
         }
         const int niy = (ms_sigma(E, cur, &nxt) <= 0 || ny == 1) ? 1 : ny;
-        const Tab t = eg_tab(b, slot1, draw, nxt.ist);
+        TT t;
+        if (lt)
+            t = *lt;
+        else {
+            const Tab tg = eg_tab(b, slot1, draw, nxt.ist);
+            t.M = (decltype(t.M))tg.M, t.C = (decltype(t.C))tg.C, t.V = (decltype(t.V))tg.V;  // (TT == Tab here)
+            t.TH = tg.TH, t.D = tg.D, t.len = tg.len, t.thlen = tg.thlen;
+        }
         if (t.len < 2) {
             status = -10;
             break;
@@ -552,7 +564,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                 double An = last;
                 if (can) {
                     An = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, n);
-                    r = eg_lane_eval(b, &E, &cur, slot1, draw, An);
+                    r = (full && staged) ? eg_lane_eval<TabL>(b, &E, &cur, slot1, draw, An, &ltab) : eg_lane_eval<Tab>(b, &E, &cur, slot1, draw, An);
                 }
                 {   // phase 1: what every wave found, in batch order
                     const unsigned long long canm = __ballot(can);
@@ -896,14 +908,43 @@ static __device__ __forceinline__ int eg_second_bracket(double x, int i, double 
     return (x < m2) ? 0 : ((x >= mlast2) ? n1 - 3 : i - 1);
 }
 
-// eg_term + eg_next_value for keep == 1 with the M column in LDS and one search (see above)
+// eg_bracket(x, g, n, 0) on a NON-DECREASING column, starting from a hint: the bracket of a neighbouring asset point for the
+// same next state and shock node.  The search returns the last row i in [1, n-3] with g[i] <= x (0 below g[1], n-2 from
+// g[n-2] on), which on an ordered column is unique -- however it is found.  Cash-in-hand moves by less than a table row or two
+// from one asset point to the next, so a step or two from the neighbour's bracket replaces log2(n) dependent reads; after
+// EG_NEAR_STEPS steps (the hint was far off) or for a NaN the full search decides.
+#ifndef EG_NEAR_STEPS
+#define EG_NEAR_STEPS 6
+#endif
+template <class P> static __device__ __forceinline__ int eg_bracket_near(double x, P g, int n, int hint)
+{
+    if (x < g[1]) return 0;
+    if (x >= g[n - 2]) return n - 2;
+    int i = min(max(hint, 1), n - 3);
+    if (g[i] <= x) {
+        for (int k = 0; k < EG_NEAR_STEPS; k++) {
+            if (!(g[i + 1] <= x)) return i;  // (i + 1 <= n - 2 and x < g[n-2]: the scan stays inside)
+            i++;
+        }
+    } else if (g[i] > x) {
+        for (int k = 0; k < EG_NEAR_STEPS; k++) {
+            i--;
+            if (g[i] <= x) return i;         // (g[1] <= x: the scan stops at row 1 at the latest)
+        }
+    }
+    return eg_bracket(x, g, n, 0);
+}
+
+// eg_term + eg_next_value for keep == 1 with the M column in LDS and one search (see above).  ibr: nullptr, or in: the
+// bracket of the neighbouring asset point (< 0: none), out: this point's.
 static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_ldsd *M, const Tab &t, const ms_pv *cur, ms_pv *nxt,
-                                                     double pr1, double *t_rhs, double *t_evf)
+                                                     double pr1, double *t_rhs, double *t_evf, int *ibr = nullptr)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const double x = nxt->cash;
     const int n1 = t.len;
-    const int i = eg_bracket(x, M, n1, 0);
+    const int i = (ibr && *ibr >= 0) ? eg_bracket_near(x, M, n1, *ibr) : eg_bracket(x, M, n1, 0);
+    if (ibr) *ibr = i;
     const double mlast = M[n1 - 1], mfirst = M[1];
     // rows i and i+1 of C and of V in ONE round of global reads: away from the table's ends valuefunc's bracket is the same
     // pair of rows (j+1 == i below), and a lane that waits twice per evaluation waits half as often
@@ -972,12 +1013,14 @@ static __device__ __forceinline__ int eg_bracket_sampled(double x, const eg_ldsd
 
 static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const eg_ldsd *S, int ns, int stride, const eg_ldsd *edge,
                                                          const Tab &t, const ms_pv *cur, ms_pv *nxt, double pr1, double *t_rhs,
-                                                         double *t_evf)
+                                                         double *t_evf, int *ibr = nullptr)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const double x = nxt->cash;
     const int n1 = t.len;
-    const int i = eg_bracket_sampled(x, S, ns, stride, t.M, n1, edge);
+    // (with a neighbour's bracket at hand: a step or two in the global column, the lines the neighbour just read)
+    const int i = (ibr && *ibr >= 0) ? eg_bracket_near(x, t.M, n1, *ibr) : eg_bracket_sampled(x, S, ns, stride, t.M, n1, edge);
+    if (ibr) *ibr = i;
     const double mlast = edge[3], mfirst = edge[0];
     // (rows i and i+1 of M, C and V in one round of global reads, see eg_term_lds)
     const double Mi = t.M[i], Mi1 = t.M[i + 1], Ci = t.C[i], Ci1 = t.C[i + 1], Vi = t.V[i], Vi1 = t.V[i + 1];
@@ -1038,9 +1081,13 @@ __global__ void __launch_bounds__(GRID_BS) k_sortcheck(const Batch *bp_, int it)
 #ifndef GRID_MINW
 #define GRID_MINW 1  // (experiments: waves per SIMD k_grid_lds is compiled for; 8 = at most 64 VGPRs)
 #endif
-__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp_, int it, int lrows)
+// PPL: consecutive asset points per lane.  1: a lane per point.  More (batches with points to spare): the lane evaluates its
+// points side by side -- (next state, shock node) outside, the points inside, every point with its own sums, so the order of
+// accumulation per point is the reference's -- and a point starts its bracket search from its predecessor's bracket
+// (eg_bracket_near): the verdict of round 2 on this kernel was "issue-bound on integer work", four of five issue slots
+// address arithmetic and compares of searches that land a row or two from where the neighbouring point's search landed.
+template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(BatchRef b, int it, int lrows)
 {
-    BatchRef b = EG_BATCH_REF(bp_);
     EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
     __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded
     __shared__ int gl_stride, gl_ns[MS_NST];  // every gl_stride-th row is staged (1: whole columns); staged entries per state
@@ -1049,7 +1096,7 @@ __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp
     __shared__ int gl_niy[MS_NST];
     const int combo = blockIdx.y;
     const int id = combo % MS_ND, ist = (combo / MS_ND) % MS_NST, draw = b.order[b.draw0 + combo / (MS_ND * MS_NST)];
-    const int n = blockIdx.x * GRID_BS + threadIdx.x + 1;
+    const int n = (blockIdx.x * GRID_BS + threadIdx.x) * PPL + 1;  // the lane's first point
     if (b.status[draw]) return;
     const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND + id];
     if (!P.active || !P.grid) return;  // (uniform over the workgroup)
@@ -1152,96 +1199,151 @@ __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp
     if (n >= b.g.ngridm) return;
     GridLims L;
     L.lim1 = P.lim1, L.lim2 = P.lim2, L.lim3 = P.lim3, L.lim3p = P.lim3p, L.k3 = P.k3, L.ntogenerate = P.ntogenerate;
-    const double A = eg_grid_A(&E, &cur, L, 0, P.A0, n);
-    LaneEval r;
-    if (!fast)
-        r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
-    else {  // eg_lane_eval with the staged columns
-        double rhs = 0, evf = 0, checksum = 0, c1 = 1.0;
-        int status = 0, terr = 0, cnt = 0;
-        r.bist = 0;
-        r.bshock = r.bcash = 0;
+    const int np = min(PPL, b.g.ngridm - n);  // points of this lane
+    double A[PPL];
+    LaneEval r[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) A[j] = (j < np) ? eg_grid_A(&E, &cur, L, 0, P.A0, n + j) : 0.0;
+    if (!fast) {
+#pragma unroll
+        for (int j = 0; j < PPL; j++)
+            if (j < np) r[j] = eg_lane_eval(b, &E, &cur, slot1, draw, A[j]);
+    } else {  // eg_lane_eval with the staged columns, the lane's points side by side
+        double rhs[PPL], evf[PPL], checksum[PPL], c1[PPL];
+        int cnt[PPL], done[PPL];  // done: the point has left the loops (c1 <= 0, evf = -inf: :556,569,572; a hard error)
+        int status[PPL], terr[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            rhs[j] = evf[j] = checksum[j] = 0, c1[j] = 1.0, cnt[j] = 0, done[j] = (j < np) ? 0 : 1, status[j] = 0, terr[j] = 0;
+            r[j].bist = 0, r[j].bshock = r[j].bcash = 0;
+        }
         ms_pv nxt;
         nxt.it = it + 1;
         nxt.id = 0;
         nxt.cash = 0;
         nxt.shock = 0;
-        nxt.savings = A;
+        nxt.savings = A[0];
         for (nxt.ist = 0; nxt.ist < MS_NST; nxt.ist++) {
+            bool all_done = true;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) all_done = all_done && done[j];
+            if (all_done) break;
             if (ms_feasible(&E, &nxt) != 1) continue;
-            double pr1pre = 0;
-            if (MS_OPTIM_TRPRNOSH) {
-                pr1pre = ms_trpr(&E, &cur, &nxt, &terr);
-                if (pr1pre == 0.0) continue;
+            // transition probability and number of nodes per point (they may depend on savings); a point whose probability
+            // is zero skips the state (:501-508)
+            double pr1pre[PPL];
+            int niyj[PPL], niymax = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                pr1pre[j] = 0, niyj[j] = 0;
+                if (done[j]) continue;
+                nxt.savings = A[j];
+                if (MS_OPTIM_TRPRNOSH) {
+                    pr1pre[j] = ms_trpr(&E, &cur, &nxt, &terr[j]);
+                    if (pr1pre[j] == 0.0) continue;
+                }
+                niyj[j] = MS_SHOCK_NODES_SHARED ? gl_niy[nxt.ist] : ((ms_sigma(&E, &cur, &nxt) <= 0 || ny == 1) ? 1 : ny);
+                niymax = max(niymax, niyj[j]);
             }
-            const int niy = MS_SHOCK_NODES_SHARED ? gl_niy[nxt.ist] : ((ms_sigma(&E, &cur, &nxt) <= 0 || ny == 1) ? 1 : ny);
+            if (niymax == 0) continue;
             const Tab t = eg_tab(b, slot1, draw, nxt.ist);
-            if (t.thlen > b.g.nthrhmax || t.thlen < 1) {
-                status = -2707;
-                break;
+            if (t.thlen > b.g.nthrhmax || t.thlen < 1) {  // (the points that reach this state stop here)
+#pragma unroll
+                for (int j = 0; j < PPL; j++)
+                    if (niyj[j] > 0) status[j] = -2707, done[j] = 1;
+                continue;
             }
             const eg_ldsd *M = LM + gl_off[nxt.ist];
             const int ns = gl_ns[nxt.ist];
             const eg_ldsd *edge = (const eg_ldsd *)gl_edge + 4 * nxt.ist;
-            for (int iy = 0; iy < niy; iy++) {
-                double pr1;
-                if (MS_SHOCK_NODES_SHARED)
-                    nxt.shock = gl_shock[nxt.ist * EG_GRID_NYMAX + iy];
-                else
-                    nxt.shock = (niy == 1) ? eg_shock_mean(&E, &cur, &nxt) : eg_shock_node(&E, &cur, &nxt, b.qz[iy]);
-                pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(&E, &cur, &nxt, &terr);
-                if (niy != 1) pr1 *= b.qw[iy];
-                if (pr1 == 0.0) continue;
-                checksum += pr1;
-                cnt++;
-                double t_rhs, t_evf;
-                c1 = (stride > 1) ? eg_term_sampled(&E, M, ns, stride, edge, t, &cur, &nxt, pr1, &t_rhs, &t_evf)
-                                  : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf);
-                if (c1 <= 0) break;
-                rhs += t_rhs;
-                evf += t_evf;
-                if (evf == -INFINITY) break;
-            }
-            if (c1 <= 0 || evf == -INFINITY) {
-                r.bist = nxt.ist;
-                r.bshock = nxt.shock;
-                r.bcash = nxt.cash;
-                break;
+            for (int iy = 0; iy < niymax; iy++) {
+                int hint = -1;  // the bracket of the previous point of this lane for this (state, node)
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    if (done[j] || iy >= niyj[j]) continue;
+                    nxt.savings = A[j];
+                    if (MS_SHOCK_NODES_SHARED)
+                        nxt.shock = gl_shock[nxt.ist * EG_GRID_NYMAX + iy];
+                    else
+                        nxt.shock = (niyj[j] == 1) ? eg_shock_mean(&E, &cur, &nxt) : eg_shock_node(&E, &cur, &nxt, b.qz[iy]);
+                    double pr1 = MS_OPTIM_TRPRNOSH ? pr1pre[j] : ms_trpr(&E, &cur, &nxt, &terr[j]);
+                    if (niyj[j] != 1) pr1 *= b.qw[iy];
+                    if (pr1 == 0.0) continue;
+                    checksum[j] += pr1;
+                    cnt[j]++;
+                    double t_rhs, t_evf;
+                    c1[j] = (stride > 1) ? eg_term_sampled(&E, M, ns, stride, edge, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr)
+                                         : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr);
+                    if (c1[j] > 0) {
+                        rhs[j] += t_rhs;
+                        evf[j] += t_evf;
+                    }
+                    if (c1[j] <= 0 || evf[j] == -INFINITY) {
+                        done[j] = 1;
+                        r[j].bist = nxt.ist;
+                        r[j].bshock = nxt.shock;
+                        r[j].bcash = nxt.cash;
+                    }
+                }
             }
         }
-        if (terr) status = -25;
-        if (status == 0) {
-            if (c1 <= 0)
-                status = 1;
-            else if (evf == -INFINITY)
-                status = 2;
-            else if (fabs(checksum - 1) > EG_TOL)
-                status = -11;
-        }
-        r.status = status;
-        r.cnt = cnt;
-        if (status == 0) {
-            rhs *= ms_discount(&E, &cur);
-            r.M = A + ms_utility_marginal_inverse(&E, &cur, rhs);
-            r.C = r.M - A;
-            r.V = ms_utility(&E, &cur, r.C) + ms_discount(&E, &cur) * evf;
-            r.R = r.M;
-        } else {
-            r.M = NAN;
-            r.C = r.V = 0;
-            r.R = (status == 1) ? b.g.a0 - 1 : r.bcash;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if (j >= np) continue;
+            int st = status[j];
+            if (terr[j]) st = -25;
+            if (st == 0) {
+                if (c1[j] <= 0)
+                    st = 1;
+                else if (evf[j] == -INFINITY)
+                    st = 2;
+                else if (fabs(checksum[j] - 1) > EG_TOL)
+                    st = -11;
+            }
+            r[j].status = st;
+            r[j].cnt = cnt[j];
+            if (st == 0) {
+                const double rr = rhs[j] * ms_discount(&E, &cur);
+                r[j].M = A[j] + ms_utility_marginal_inverse(&E, &cur, rr);
+                r[j].C = r[j].M - A[j];
+                r[j].V = ms_utility(&E, &cur, r[j].C) + ms_discount(&E, &cur) * evf[j];
+                r[j].R = r[j].M;
+            } else {
+                r[j].M = NAN;
+                r[j].C = r[j].V = 0;
+                r[j].R = (st == 1) ? b.g.a0 - 1 : r[j].bcash;
+            }
         }
     }
     const size_t o = eg_cand(b, draw, ist, id) + n;
-    if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
-    b.cCnt[o] = r.cnt;
-    b.cSt[o] = r.status;
-    b.cR[o] = r.R;
-    b.cM[o] = r.M;
-    if (r.status == 0) {
-        b.cC[o] = r.C;
-        b.cV[o] = r.V;
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        if (j >= np) continue;
+        if (r[j].status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
+        b.cCnt[o + j] = r[j].cnt;
+        b.cSt[o + j] = r[j].status;
+        b.cR[o + j] = r[j].R;
+        b.cM[o + j] = r[j].M;
+        if (r[j].status == 0) {
+            b.cC[o + j] = r[j].C;
+            b.cV[o + j] = r[j].V;
+        }
     }
+}
+
+#ifndef GRID_PPL
+#define GRID_PPL 4  // asset points per lane of k_grid_lds_n (the form for batches with points to spare)
+#endif
+__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp_, int it, int lrows)
+{
+    eg_grid_lds_body<1>(EG_BATCH_REF(bp_), it, lrows);
+}
+#ifndef GRID_N_MINW
+#define GRID_N_MINW 1  // (the lane's points side by side want registers: 133 VGPRs by default, three waves per SIMD)
+#endif
+__global__ void __launch_bounds__(GRID_BS, GRID_N_MINW) k_grid_lds_n(const Batch *bp_, int it, int lrows)
+{
+    eg_grid_lds_body<GRID_PPL>(EG_BATCH_REF(bp_), it, lrows);
 }
 
 // k_grid for small batches: 16 lanes per grid point, a lane per shock node (eg_wave_expectation with groups of 16),
@@ -1609,12 +1711,33 @@ template <class ANA>
 static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const double *im, const double *ic, const double *iv, const int *ifn,
                                      const eg_ldsi *fstart, const eg_ldsi *dims, double *om, double *oc, double *ov, int *of,
                                      int *rank, int *sh, int *oob, int *dbg, int *cls, int *fused, ANA ana, eg_ldsd *lkeys,
-                                     int lkeys_cap)
+                                     int lkeys_cap, eg_ldss *lperm = nullptr, eg_ldsi *lcls = nullptr, int lperm_cap = 0)
 {
+    // The sorted stream is written in TWO steps.  A point's rank is where it goes, and neighbouring threads hold neighbouring
+    // points of ONE list, whose ranks are interleaved with the other lists' -- written straight to (om, oc, ov, of, cls)[rank]
+    // every store instruction of a wave fills half of each cache line it touches, the other half arrives from another wave
+    // much later, and with thousands of workgroups in flight the half-written lines are evicted in between: measured on
+    // C2 x 4096 (profiles/r03_a_*), the throughput path's sort ran 3x SLOWER with seven workgroups per CU than with one.
+    // So step one scatters only the inverse permutation perm[rank] = input index (and the class word) -- in LDS when the
+    // caller has room (lperm, lcls: npts <= lperm_cap < 65536), else into `of` (one 4-byte array instead of six arrays) --
+    // and step two walks the sorted positions in order: coalesced stores, gathered loads from lists that are read nearly
+    // in sequence.  rank[i] itself is indexed by the input and always written coalesced.
+    const bool perm_lds = lperm != nullptr && npts <= lperm_cap && npts <= lkeys_cap && npts < 65536;  // (lcls holds lkeys_cap words)
+    int Pnet = 1;  // a bitonic network over the inverse permutation needs a power of two of entries
+    while (Pnet < npts) Pnet <<= 1;
+    const bool net_ok = perm_lds && Pnet <= lperm_cap;
     // lkeys: the workgroup's dynamic LDS, lkeys_cap doubles.  A stream that is too long to be sorted and walked in LDS
     // (32 B per point) often still fits with its M keys alone (8 B per point: C3's 12 000-point primary stream, 96 KB):
     // the binary searches of the rank merge then run on LDS, and the V keys are read from global memory only at M ties
     // and at the bracket of the classification.
+#ifdef EGDST_TPSTAMPS  // diagnostic: where a global-memory sort spends its time (dbg as 8 x u64: 0 staging + order check, 1 presort
+    unsigned long long tp_t_ = wall_clock64();  // of lists out of order, 2 ranks, 3 tail; 4 sorts, 5 sorts with a list out of order)
+#define TPST(k) do { __syncthreads(); if (threadIdx.x == 0 && dbg) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)dbg + (k), n_ - tp_t_); tp_t_ = n_; } } while (0)
+#define TPCNT(k, v) do { if (threadIdx.x == 0 && dbg) atomicAdd((unsigned long long *)dbg + (k), (unsigned long long)(v)); } while (0)
+#else
+#define TPST(k)
+#define TPCNT(k, v)
+#endif
     const bool lds_keys = lkeys != nullptr && npts <= lkeys_cap;
     // (longer still: every sk-th key, a sampled index -- see eg_rank_classify_run)
     const int sk = (lkeys != nullptr && !lds_keys && lkeys_cap >= 64) ? (npts + lkeys_cap - 1) / lkeys_cap : 0;
@@ -1629,6 +1752,9 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
         if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
     bad = blk_sum(bad, sh);
+    TPST(0);
+    TPCNT(4, 1);
+    TPCNT(5, bad ? 1 : 0);
     if (bad) {
         // A list out of comp1 order is out of order LOCALLY: the double point of a kink (x + 1e-10) has overtaken the next
         // grid point or two -- on fine grids (C5: 32 768 points, spacing below 1e-10 near a0) that happens in many periods,
@@ -1637,7 +1763,9 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         // strictly out of order, so fully tied points keep their input order (what the reference's stable qsort gives), and
         // the final sorted stream is the same.  (The input arrays are the kernel's own work arrays.)
         double *wm = (double *)im, *wc = (double *)ic, *wv = (double *)iv;
-        for (int round = 0; round < 64 && bad; round += 2) {
+        // (with the LDS network below at hand, a few rounds: what they do not repair is not a local disorder)
+        const int max_rounds = net_ok ? 8 : 64;
+        for (int round = 0; round < max_rounds && bad; round += 2) {
             for (int par = 0; par < 2; par++) {
                 for (int i = 2 * (int)threadIdx.x + par; i + 1 < npts; i += 2 * ENV_BS) {
                     if (ifn[i] != ifn[i + 1]) continue;
@@ -1655,6 +1783,20 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
                 if (ifn[i] == ifn[i - 1] && !pt_before(wm[i - 1], wv[i - 1], ifn[i - 1], i - 1, wm[i], wv[i], ifn[i], i)) b2 = 1;
             bad = blk_sum(b2, sh);
         }
+#ifdef EGDST_EMU
+        if (threadIdx.x == 0 && getenv("EGDST_TRACE_BAD")) {
+            int nb = 0, fb = -1;
+            for (int i = 1; i < npts; i++)
+                if (ifn[i] == ifn[i - 1] && !pt_before(wm[i - 1], wv[i - 1], ifn[i - 1], i - 1, wm[i], wv[i], ifn[i], i)) {
+                    nb++;
+                    if (fb < 0) fb = i;
+                }
+            fprintf(stderr, "sort: lists out of order npts=%d nf=%d still_bad=%d (pairs %d)", npts, nf, bad, nb);
+            if (fb >= 0)
+                fprintf(stderr, " first at %d f=%d: (%.17g, %.17g) then (%.17g, %.17g)", fb, ifn[fb], wm[fb - 1], wv[fb - 1], wm[fb], wv[fb]);
+            fprintf(stderr, "\n");
+        }
+#endif
         if (lds_keys) {  // (the staged M keys follow the lists)
             __syncthreads();
             for (int i = threadIdx.x; i < npts; i += ENV_BS) lkeys[i] = im[i];
@@ -1665,6 +1807,41 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
             __syncthreads();
         }
     }
+    // Still out of order: a list that is not merely locally disordered -- a guess stream that re-based (k_fixup) runs up to
+    // mmax, drops back and climbs again, and the reference hands such lists to qsort like any other (egdst_solver.c:1240).
+    // Counting ranks (below) is quadratic: 2.8 ms for a 2000-point stream, which 0.4 % of the C2 cells need -- one in nearly
+    // every launch of a few hundred cells, so that EVERY launch lasted 2.8 ms (measured, profiles/r03_*).  With the inverse
+    // permutation in LDS the whole stream goes through a bitonic network on the input indices instead (keys looked up in
+    // LDS, V keys in global memory only at M ties): a fraction of a millisecond.
+    bool networked = false;
+    if (bad && net_ok) {
+        const int P = Pnet;
+        {
+            for (int i = threadIdx.x; i < P; i += ENV_BS) lperm[i] = (unsigned short)(i < npts ? i : 0xffff);  // padding sorts last
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = threadIdx.x; i < P; i += ENV_BS) {
+                        const int q = i ^ j;
+                        if (q > i) {
+                            const int a = lperm[i], z = lperm[q];
+                            bool zfirst;  // does the entry at q precede the entry at i?
+                            if (a == 0xffff)
+                                zfirst = (z != 0xffff);
+                            else if (z == 0xffff)
+                                zfirst = false;
+                            else
+                                zfirst = pt_before(lds_keys ? (double)lkeys[z] : im[z], iv[z], ifn[z], z, lds_keys ? (double)lkeys[a] : im[a], iv[a],
+                                                   ifn[a], a);
+                            if (((i & k) == 0) == zfirst) lperm[i] = (unsigned short)z, lperm[q] = (unsigned short)a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            networked = true;
+        }
+    }
+    TPST(1);
     double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
     *fused = 0;
     if (!bad && cls) {
@@ -1688,12 +1865,14 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
 #endif
     if (!bad && nact == 2) {
         auto emit = [&](int r, int i, int f, double m, double v, int w) {
-            if (cls) cls[r] = w;
             rank[i] = r;
-            om[r] = m;
-            oc[r] = ic[i];
-            ov[r] = v;
-            of[r] = f;
+            if (perm_lds) {
+                lperm[r] = (unsigned short)i;
+                if (cls) lcls[r] = w;
+            } else {
+                of[r] = i;
+                if (cls) cls[r] = w;
+            }
         };
         if (lds_keys)
             eg_merge2_classify(npts, nf, ga, (int)fstart[ga], (int)dims[ga], gb, (int)fstart[gb], (int)dims[gb], (const eg_ldsd *)lkeys, iv,
@@ -1703,13 +1882,13 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
                                kbound, ana, emit);
     }
     for (int i0 = ENV_RK * (int)threadIdx.x; i0 < npts && !bad && nact != 2; i0 += ENV_RK * ENV_BS) {  // a run of consecutive points per round
-        double m[ENV_RK], v[ENV_RK], c[ENV_RK];
+        double m[ENV_RK], v[ENV_RK];
         int f[ENV_RK], r[ENV_RK], w[ENV_RK];
         const int n = min(ENV_RK, npts - i0);
 #pragma unroll
         for (int k = 0; k < ENV_RK; k++) {
-            m[k] = v[k] = c[k] = 0, f[k] = 0;
-            if (k < n) m[k] = im[i0 + k], v[k] = iv[i0 + k], c[k] = ic[i0 + k], f[k] = ifn[i0 + k];
+            m[k] = v[k] = 0, f[k] = 0;
+            if (k < n) m[k] = im[i0 + k], v[k] = iv[i0 + k], f[k] = ifn[i0 + k];
         }
         if (lds_keys)
             eg_rank_classify_run(i0, n, nf, (const eg_ldsd *)lkeys, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w);
@@ -1723,15 +1902,18 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
                 *oob = 1;
                 continue;
             }
-            if (cls) cls[r[k]] = w[k];
             rank[i0 + k] = r[k];
-            om[r[k]] = m[k];
-            oc[r[k]] = c[k];
-            ov[r[k]] = v[k];
-            of[r[k]] = f[k];
+            if (perm_lds) {
+                lperm[r[k]] = (unsigned short)(i0 + k);
+                if (cls) lcls[r[k]] = w[k];
+            } else {
+                of[r[k]] = i0 + k;
+                if (cls) cls[r[k]] = w[k];
+            }
         }
     }
-    for (int i = threadIdx.x; i < npts && bad; i += ENV_BS) {  // (lists still out of order after the presort: counting)
+    TPST(2);
+    for (int i = threadIdx.x; i < npts && bad && !networked; i += ENV_BS) {  // (lists still out of order after the presort: counting)
         const double m = im[i], v = iv[i];
         const int f = ifn[i];
         int r = 0;
@@ -1742,10 +1924,27 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
             continue;
         }
         rank[i] = r;
-        om[r] = m;
-        oc[r] = ic[i];
-        ov[r] = v;
-        of[r] = f;
+        if (perm_lds)
+            lperm[r] = (unsigned short)i;
+        else
+            of[r] = i;
+    }
+    __syncthreads();
+    // step two: the sorted stream, position by position (see the head of this function).  `of` may hold the permutation:
+    // every position is read and rewritten by the same thread.
+    if (!*oob) {
+        for (int r = threadIdx.x; r < npts; r += ENV_BS) {
+            const int i = perm_lds ? (int)lperm[r] : of[r];
+            if (i < 0 || i >= npts) {  // (a rank taken twice leaves a hole: never expected, the walk would read garbage)
+                *oob = 1;
+                continue;
+            }
+            om[r] = im[i];
+            oc[r] = ic[i];
+            ov[r] = iv[i];
+            of[r] = ifn[i];
+            if (perm_lds && cls && *fused) cls[r] = lcls[r];
+        }
     }
     __syncthreads();
     // rank[fstart[f]+k] must be the sorted position of the k-th point of f IN SORTED ORDER (the reference builds
@@ -1770,6 +1969,7 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         }
         __syncthreads();
     }
+    TPST(3);
 #ifdef EGDST_VERIFY_SORT
     // diagnostic build: the output must be a permutation of the input in comp1 order
     for (int i = threadIdx.x; i < npts && !bad; i += ENV_BS) {
@@ -2038,9 +2238,9 @@ struct WalkJob {  // what one envelope walk needs besides the sorted stream
 // every lane of it holds the same values)
 // SEG = false: the walk is never cut into segments -- the throughput path (k_tp_walk), where a whole cell belongs to one
 // wave and the batch, not the cell, provides the parallelism; the planning, checking and gathering code is compiled out.
-template <bool L, bool SEG = true>
+template <int L, bool SEG = true>
 static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &j, const typename EgMem<L>::D *m,
-                                                const typename EgMem<L>::D *c, const typename EgMem<L>::D *v,
+                                                const typename EgMem<L>::DC *c, const typename EgMem<L>::D *v,
                                                 const typename EgMem<L>::S *f, const typename EgMem<L>::S *posl,
                                                 typename EgMem<L>::I *cls, int *err, int *n, int *nth, int classified)
 {
@@ -2756,7 +2956,7 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
             {
                 int we = 0, wn = 0, wm = 0;
                 job.wM = qM, job.wV = qV, job.wC = qC, job.wcap = (int)W;   // (the global sort arrays are idle on this path)
-                run_walk<true>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm, fused);  // sorted M, C, V
+                run_walk<1>(&E, job, R2, R1, R3, Lf, posl, Lq, &we, &wn, &wm, fused);  // sorted M, C, V
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         } else if (pass == 0) {
@@ -2782,7 +2982,7 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
                 int we = 0, wn = 0, wm = 0;
                 // (the unsorted input of a secondary envelope is dead once it is sorted; the primary's input lives in p*)
                 job.wM = sM, job.wV = sV, job.wC = sC, job.wcap = (int)W;
-                run_walk<false>(&E, job, qM, qC, qV, qF, rank, gcls, &we, &wn, &wm, fused);
+                run_walk<0>(&E, job, qM, qC, qV, qF, rank, gcls, &we, &wn, &wm, fused);
                 if (tid < WAVE) s_err = we, s_n = wn, s_m = wm;
             }
         }
@@ -2909,13 +3109,32 @@ static_assert(MS_ND <= TP_NF, "TP_NF must hold one function per choice");
 #ifndef TP_SORT_MINW
 #define TP_SORT_MINW 8  // (at most 64 VGPRs: eight waves per SIMD; the default build came out at 65)
 #endif
-__global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp_, int it)
+// b.defer[cell] may be set by ANOTHER workgroup of the same launch at any moment (the other choice of the cell): the waves
+// of a workgroup must not read it each for themselves -- a return that not every wave takes leaves the others at the next
+// barrier for ever.  One thread reads, everybody uses what it saw.
+#define TP_DEFERRED_UNIFORM(S, cell) \
+    ([&]() -> int {                     \
+        __syncthreads();                \
+        if (threadIdx.x == 0) (S)->res[0] = b.defer[cell]; \
+        __syncthreads();                \
+        return (S)->res[0];             \
+    }())
+
+// static LDS of a workgroup of the path, shared by its phases (the fused kernels run them one after the other)
+struct TpShared {
+    int sh[ENV_MAXBS + 2];                                   // scan scratch of the block-wide helpers
+    int fstart[TP_NF], fdims[TP_NF], fcur[TP_NF], fmark[TP_NF];
+    int stack[2 * (TP_NF + 2)];
+    double evfa0[MS_ND];
+    int oob, res[3];
+};
+
+// bxi: cell slot of the group * MS_ND + choice
+static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpShared *S)
 {
-    BatchRef b = EG_BATCH_REF(bp_);
-    __shared__ int sh[ENV_MAXBS + 2];
-    __shared__ int s_fstart[TP_NF];
-    __shared__ int s_oob;
-    const int bx_ = (int)blockIdx.x / MS_ND, id = (int)blockIdx.x % MS_ND;
+    int *const sh = S->sh, *const s_fstart = S->fstart;
+    int &s_oob = S->oob;
+    const int bx_ = bxi / MS_ND, id = bxi % MS_ND;
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
@@ -3045,22 +3264,28 @@ __global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp
     }
     if (tid == 0) R->active = 1, R->cnt = cnt, R->nfold = nfold, R->evfa0 = evfa0, R->evals = evals;
 }
+__global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp_, int it)
+{
+    __shared__ TpShared S;
+    tp_prep(EG_BATCH_REF(bp_), it, (int)blockIdx.x, &S);
+}
 
 // stage 0: the pieces of one folded choice list (secondary envelope); stage 1: the choice lists of a cell (primary).
 // lkcap: M keys that fit the dynamic LDS.
-__global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap)
+// bxi: stage 0: cell slot * MS_ND + choice; stage 1: cell slot
+static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int bxi, TpShared *S, double *dynlds)
 {
-    BatchRef b = EG_BATCH_REF(bp_);
-    EG_DYN_LDS(dynlds);
-    __shared__ int sh[ENV_MAXBS + 2];
-    __shared__ int s_fstart[TP_NF], s_fdims[TP_NF];
-    __shared__ double s_evfa0[MS_ND];
-    __shared__ int s_oob;
-    const int bx_ = stage ? (int)blockIdx.x : (int)blockIdx.x / MS_ND, id = stage ? 0 : (int)blockIdx.x % MS_ND;
+    int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims;
+    double *const s_evfa0 = S->evfa0;
+    int &s_oob = S->oob;
+    const int bx_ = stage ? bxi : bxi / MS_ND, id = stage ? 0 : bxi % MS_ND;
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
-    if (b.defer[cell]) return;  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
+    if (TP_DEFERRED_UNIFORM(S, cell)) return;  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
+#ifdef EGDST_TPSTAMPS
+    const unsigned long long tpk_t0_ = wall_clock64();
+#endif
     TpRec *R = b.tprec + cell * MS_ND + id;
     ms_env E = eg_env(b, draw);
     const size_t Wcell = (size_t)(MS_ND + 1) * b.g.Cp;
@@ -3114,6 +3339,9 @@ __global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp
         iM = pM, iC = pC, iV = pV, iF = pF;
     }
     __syncthreads();
+#ifdef EGDST_TPSTAMPS
+    if (tid == 0) atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 6, wall_clock64() - tpk_t0_);
+#endif
     const int sec_id_ = sec_id;
     const double sec_ev_ = sec_ev;
     auto ana = [&](int g, double x) -> double {  // value of function g before its first point (env_analytic / env_evf)
@@ -3124,9 +3352,30 @@ __global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp
         return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
     };
     int fused = 0;
-    blk_rank_sort(npts, nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw, gcls, &fused, ana,
-                  (eg_ldsd *)dynlds, lkcap);
+    // dynamic LDS: lkcap M keys (8 B) and class words (4 B), and the inverse permutation of the sort (2 B per entry, the next
+    // power of two of lkcap entries: room for the bitonic network of a stream of any length up to lkcap)
+    eg_ldsd *lkeys = (eg_ldsd *)dynlds;
+    int lpcap = 1;
+    while (lpcap < lkcap) lpcap <<= 1;
+#ifdef EGDST_EMU
+    eg_ldsi *lcls = (eg_ldsi *)(lkeys + lkcap + 8);   // (poisoned gaps between the regions, see k_envelope)
+    eg_ldss *lperm = (eg_ldss *)(lcls + lkcap + 16);
     __syncthreads();
+    if (threadIdx.x == 0) {
+        EG_EMU_UNPOISON_DYN(dynlds);
+        EG_EMU_POISON(lkeys + lkcap, 64), EG_EMU_POISON(lcls + lkcap, 64);
+    }
+    __syncthreads();
+#else
+    eg_ldsi *lcls = (eg_ldsi *)(lkeys + lkcap);
+    eg_ldss *lperm = (eg_ldss *)(lcls + lkcap);
+#endif
+    blk_rank_sort(npts, nf, iM, iC, iV, iF, fstart, fdims, qM, qC, qV, qF, rank, sh, &s_oob, b.dbg + 16 * draw, gcls, &fused, ana,
+                  lkeys, lkcap, lperm, lcls, lpcap);
+    __syncthreads();
+#ifdef EGDST_TPSTAMPS
+    if (tid == 0) atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 7, wall_clock64() - tpk_t0_);
+#endif
     if (s_oob) TP_DEFER();
     if (tid == 0) {
         if (stage == 0)
@@ -3134,6 +3383,12 @@ __global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp
         else
             b.tpcell[cell].npts = npts, b.tpcell[cell].fused = fused;
     }
+}
+__global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap)
+{
+    EG_DYN_LDS(dynlds);
+    __shared__ TpShared S;
+    tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, (int)blockIdx.x, &S, (double *)dynlds);
 }
 
 // One wave per job.  stage 0: secondary envelope of a folded choice list, result written over the list it came from (dead by
@@ -3152,23 +3407,31 @@ __global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp
         }                                                                   \
         return;                                                             \
     } while (0)
-__global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_, int it, int stage, int *list, int *cnt)
+// dynlds: the sorted stream: lcap entries of M, V (8 B), class word (4 B), function id and position list (2 B).  Any number
+// of waves: all of them load the stream and classify where the sort did not, wave 0 walks.
+static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, int *list, int *cnt, int lcap, int bxi, TpShared *S, double *dynlds)
 {
-    BatchRef b = EG_BATCH_REF(bp_);
-    __shared__ int sh[ENV_MAXBS + 2];
-    __shared__ int s_fstart[TP_NF], s_fdims[TP_NF], s_fcur[TP_NF], s_fmark[TP_NF];
-    __shared__ int s_stack[2 * (TP_NF + 2)];
-    __shared__ double s_evfa0[MS_ND];
-    const int bx_ = stage ? (int)blockIdx.x : (int)blockIdx.x / MS_ND, id = stage ? 0 : (int)blockIdx.x % MS_ND;
+    int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims, *const s_fcur = S->fcur, *const s_fmark = S->fmark;
+    int *const s_stack = S->stack;
+    double *const s_evfa0 = S->evfa0;
+    const int TPW = (int)blockDim.x;
+    const int bx_ = stage ? bxi : bxi / MS_ND, id = stage ? 0 : bxi % MS_ND;
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
-    if (b.defer[cell]) {
+    if (TP_DEFERRED_UNIFORM(S, cell)) {
         if (stage == 1 && tid == 0) list[atomicAdd((unsigned *)cnt, 1u)] = bx_, atomicAdd(&b.tpstat[2 * draw + 1], 1u);
         return;
     }
     TpRec *R = b.tprec + cell * MS_ND + id;
     if (stage == 0 && (!R->active || R->nfold <= 0)) return;
+#ifdef EGDST_TPSTAMPS_WALK  // diagnostic: dbg as 8 x u64 per draw: stage*3 + {0 set-up and load, 1 the walk, 2 the rest}; 6, 7: walks per stage
+    unsigned long long tw_t_ = wall_clock64();
+#define TWST(k) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + stage * 3 + (k), n_ - tw_t_); tw_t_ = n_; } } while (0)
+    if (tid == 0) atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 6 + stage, 1ull);
+#else
+#define TWST(k)
+#endif
     ms_env E = eg_env(b, draw);
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
@@ -3199,7 +3462,7 @@ __global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_
     if (stage == 0) {
         job.npts = R->cnt + R->nfold;
         job.nf = id + R->nfold + 1;
-        for (int f = tid; f < job.nf; f += WAVE) {
+        for (int f = tid; f < job.nf; f += TPW) {
             const int a = R->fstart[f], z = (f + 1 < job.nf) ? R->fstart[f + 1] : job.npts;
             fstart[f] = (f < id) ? 0 : a;
             fdims[f] = (f < id) ? 0 : z - a;
@@ -3231,18 +3494,68 @@ __global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_
         __syncthreads();  // (every lane has read the marks)
         if (tid == 0) b.thw[tk] = b.g.Sp, b.thhw[tk] = b.g.nthrhmax;
     }
+    // The stream goes to LDS first: at a crossing the walk follows chains of dependent reads (position list -> point ->
+    // neighbour of the other function ...), a few microseconds each from global memory under load -- the one-wave walks
+    // over global memory took 230-440 us per launch (profiles/r03_*), nearly all of it in four or five such events.  The
+    // consumption column stays where it is: the walk copies it to the rows it keeps and reads it at a kink only.
+    // A stream that does not fit (a degenerate guess stream with thousands of points) is k_envelope's.
+    if (job.npts > lcap || job.npts >= 65536) {
+        if (stage == 1) TP_DEFER_LISTED();
+        TP_DEFER();
+    }
+#ifdef EGDST_EMU
+    eg_ldsd *Lm = (eg_ldsd *)dynlds, *Lv = Lm + lcap + 8;
+    eg_ldsi *Lc = (eg_ldsi *)(Lv + lcap + 8);
+    eg_ldss *Lf = (eg_ldss *)(Lc + lcap + 16), *Lp = Lf + lcap + 32;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        EG_EMU_UNPOISON_DYN(dynlds);
+        EG_EMU_POISON(Lm + lcap, 64), EG_EMU_POISON(Lv + lcap, 64), EG_EMU_POISON(Lc + lcap, 64), EG_EMU_POISON(Lf + lcap, 64);
+    }
+    __syncthreads();
+#else
+    eg_ldsd *Lm = (eg_ldsd *)dynlds, *Lv = Lm + lcap;
+    eg_ldsi *Lc = (eg_ldsi *)(Lv + lcap);
+    eg_ldss *Lf = (eg_ldss *)(Lc + lcap), *Lp = Lf + lcap;
+#endif
+    {
+        const double *gM = b.qM + wo, *gV = b.qV + wo;
+        const int *gF = b.qF + wo, *gR = b.rank + wo, *gC = b.gcls + wo;
+        for (int i0 = tid; i0 < job.npts; i0 += 4 * TPW) {  // (four rounds of loads in flight, then the stores)
+            double tm[4], tv[4];
+            int tc[4], tf[4], tr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * TPW;
+                tm[k] = tv[k] = 0, tc[k] = tf[k] = tr[k] = 0;
+                if (i < job.npts) tm[k] = gM[i], tv[k] = gV[i], tc[k] = gC[i], tf[k] = gF[i], tr[k] = gR[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * TPW;
+                if (i < job.npts) Lm[i] = tm[k], Lv[i] = tv[k], Lc[i] = tc[k], Lf[i] = (unsigned short)tf[k], Lp[i] = (unsigned short)tr[k];
+            }
+        }
+    }
+    __syncthreads();
+    TWST(0);
     int we = 0, wn = 0, wm = 0;
-    run_walk<false, false>(&E, job, b.qM + wo, b.qC + wo, b.qV + wo, b.qF + wo, b.rank + wo, b.gcls + wo, &we, &wn, &wm, classified);
+    run_walk<2, false>(&E, job, Lm, b.qC + wo, Lv, Lf, Lp, Lc, &we, &wn, &wm, classified);
+    TWST(1);
+    __syncthreads();  // (the results are wave 0's: hand them to the other waves of a fused kernel)
+    if (tid == 0) S->res[0] = we, S->res[1] = wn, S->res[2] = wm;
+    __syncthreads();
+    we = S->res[0], wn = S->res[1], wm = S->res[2];
     if (stage == 0) {
         if (we || wn >= b.g.ngridmax) TP_DEFER();  // (:884)
         if (tid == 0) R->cnt = wn;
+        TWST(2);
         return;
     }
     if (we || wn == 0) TP_DEFER_LISTED();  // (wn == 0: error 16 of k_envelope)
     const int outn = wn, outm = wm;
-    for (int i = outn + 1 + tid; i < hw_rows; i += WAVE) oM[i] = oC[i] = oV[i] = 0.0;
-    for (int i = outm + tid; i < hw_th; i += WAVE) oTH[i] = oD[i] = 0.0;
+    for (int i = outn + 1 + tid; i < hw_rows; i += TPW) oM[i] = oC[i] = oV[i] = 0.0;
+    for (int i = outm + tid; i < hw_th; i += TPW) oTH[i] = oD[i] = 0.0;
     // ---- row 0 and lengths (saveoutput :917-952; evf(a0) :730) ------------------------------------
     if (tid == 0) {
         b.thw[tk] = outn + 1;
@@ -3254,6 +3567,7 @@ __global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_
         b.tthlen[tk] = outm;
         if (evals) atomicAdd(&b.evals[draw], evals);
         atomicAdd(&b.tpstat[2 * draw], 1u);
+        TWST(2);
         unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull * (unsigned long long)outm;  // (see k_envelope)
         const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
         const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
@@ -3261,6 +3575,18 @@ __global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_
         atomicAdd(&b.algbytes[draw], by);
     }
 }
+__global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_, int it, int stage, int *list, int *cnt, int lcap)
+{
+    EG_DYN_LDS(dynlds);
+    __shared__ TpShared S;
+    tp_walk(EG_BATCH_REF(bp_), it, stage, list, cnt, lcap, (int)blockIdx.x, &S, (double *)dynlds);
+}
+
+// (Measured and not kept: the same phases FUSED into two kernels -- per (cell, choice) the list, its sort and its secondary
+//  envelope; per cell the sort of the lists and the primary envelope -- so that a launch costs the slowest chain of phases
+//  instead of the sum of the slowest workgroups of five launches.  C2 x 4096: 202 ms against 184 ms: a fused workgroup holds
+//  256 threads' registers and the walk's LDS while one of its waves walks, and the period's chain is no shorter, 512 + 348 us
+//  against 40 + 113 + 375 + 231 + 142 us.)
 #endif  // MS_ND > 1
 
 // ---------------------------------------------------------------------------------------------

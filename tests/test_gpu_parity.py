@@ -272,7 +272,7 @@ def test_throughput_envelope_path_bit_exact(name, keys, monkeypatch):
     little LDS that it works on a sampled index of them; and the path really does the cells (egdst_get_tp_stats)."""
     monkeypatch.setenv('EGDST_ENV_TP', '1')
     if keys == 'sampled_keys':
-        monkeypatch.setenv('EGDST_TP_LKCAP', '96')
+        monkeypatch.setenv('EGDST_TP_SORT_LKCAP', '96')
     m = TP_CASES[name]()
     s = gpu_solve(m)
     sol = s.solution(0)
@@ -548,6 +548,27 @@ def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
     ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
     assert ok, rep
     assert sol.nevals == ref.nevals
+
+
+@pytest.mark.parametrize('name', ['retirement2', 'occ3_n400', 'retire8', 'C2', 'deaton_n4096', 'cake_normal'])
+def test_neighbour_hinted_bracket_search_is_the_binary_search(name, monkeypatch):
+    """k_grid_lds_n (EGDST_GRID_PPL=1): a lane evaluates four consecutive asset points side by side and starts each bracket search
+    at the neighbouring point's bracket (eg_bracket_near) -- the 'search bound from the neighbour' of SURVEY section 7.  On an
+    ordered column the bracket is unique however it is found: tables, thresholds and evaluation counts equal the oracle's bit
+    for bit, with whole columns in LDS and with the sampled index (the near search then steps through the global column)."""
+    monkeypatch.setenv('EGDST_GRID_PPL', '1')
+    monkeypatch.setenv('EGDST_GRID_WIDE', '0')
+    m = {'retirement2': lambda: examples.retirement2(), 'occ3_n400': SCALED['occ3_n400'], 'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5),
+         'C2': SCALED['C2'], 'deaton_n4096': SCALED['deaton_n4096'], 'cake_normal': lambda: examples.cake_normal()}[name]()
+    ref = Oracle(m).solve()
+    for lds in ('', '96'):
+        if lds:
+            monkeypatch.setenv('EGDST_GRID_LDS', lds)
+        s = gpu_solve(m)
+        sol = s.solution(0)
+        ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+        assert ok and sol.nevals == ref.nevals, (name, lds, rep)
+        s.close()
 
 
 @pytest.mark.parametrize('name', ['cake_normal', 'retirement_mortal'])
