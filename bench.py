@@ -143,9 +143,14 @@ def pmc_metrics(workload, ndraw, kernel):
     except (OSError, ValueError):
         return {}
 
+CLASS_NAMES = ['probe', 'grid', 'k_envelope', 'regeneration', 'tp_prep', 'tp_sort0', 'tp_sort1', 'tp_walk0', 'tp_walk1']
+CLASS_KERNELS = [['k_probe'], ['k_grid_lds', 'k_grid_wide', 'k_grid', 'k_grid_lds_n'], ['k_envelope'], ['k_fixup'], ['k_tp_prep'], ['k_tp_sort'],
+                 ['k_tp_sort'], ['k_tp_walk'], ['k_tp_walk']]
+
+
 def pmc_for(workload, ndraw, cls, small=False):
     """(kernel name, counter figures) of a profile class from the committed PMC passes of this configuration"""
-    cands = {1: ['k_grid_lds', 'k_grid_wide', 'k_grid'], 2: ['k_tp_walk', 'k_envelope'], 0: ['k_probe'], 3: ['k_fixup']}[cls]
+    cands = CLASS_KERNELS[cls]
     if not small:
         for cand in cands:
             pm = pmc_metrics(workload, ndraw, cand)
@@ -154,29 +159,42 @@ def pmc_for(workload, ndraw, cls, small=False):
     return cands[0], {}
 
 
-CLASS_NAMES = ['probe', 'grid', 'envelope', 'regeneration']
-
-
-def roofline_record(workload, ndraw, kms, klaunch, algbytes, evals_step, value, small=False):
-    """the `roofline` object of one configuration from the HIP-event profile of its last solve"""
+def roofline_record(workload, ndraw, kms, klaunch, algbytes, evals_step, value, small=False, serial_ms=None):
+    """the `roofline` object of one configuration from the HIP-event profile of its last solve.  serial_ms: the same classes
+    from a solve of the same handle with ONE draw group (every kernel has the GPU to itself: no concurrent streams)."""
     dom = int(np.argmax(kms))
     avg_launch_s = (kms[dom] / max(klaunch[dom], 1)) * 1e-3
     bytes_per_launch = algbytes / max(klaunch[dom], 1)
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     dom_kernel, pm = pmc_for(workload, ndraw, dom, small)
     _, pg = pmc_for(workload, ndraw, 1, small)
-    egm_only = evals_step / (kms[1] * 1e-3) if kms[1] > 0 else None
+    grid_alone = float(serial_ms[1]) if serial_ms is not None else None
+    egm_only = evals_step / (grid_alone * 1e-3) if grid_alone else None
     return {'bound': 'hbm', 'bound_note': 'reported against HBM as the contract asks; the path is latency / issue bound, see ceilings',
             'kernel': dom_kernel, 'kernel_class': CLASS_NAMES[dom], 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
             'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
             'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches': int(klaunch[dom]),
             'valu_util': pm.get('valu_util'), 'valu_fp64_util': pm.get('valu_fp64_util'), 'lds_GBps': pm.get('lds_GBps'),
             'wave_cycles_waiting_frac': pm.get('wave_cycles_waiting_frac'), 'counters_from': pm.get('source'),
-            'ceilings': {'egm_only_evals_per_s': egm_only,
+            'ceilings': {'note': 'egm_only: the evaluations of a step / the device time of the grid kernel when it has the GPU to itself '
+                                 '(one draw group, no concurrent streams); kernel_ms_one_group: every class measured that way',
+                         'egm_only_evals_per_s': egm_only,
                          'pipeline_frac_of_egm_only': (value / egm_only) if egm_only else None,
-                         'grid_kernel_ms_summed': float(kms[1]),
+                         'kernel_ms_one_group': {n: float(v) for n, v in zip(CLASS_NAMES, serial_ms)} if serial_ms is not None else None,
                          'grid_kernel_issue_util': pg.get('valu_util'), 'grid_kernel_fp64_util': pg.get('valu_fp64_util'),
                          'grid_kernel_fp64_share_of_valu': (pg['valu_fp64_util'] / pg['valu_util']) if pg.get('valu_util') else None}}
+
+
+def serial_profile(solver):
+    """one more solve of the handle's current draws with ONE draw group, HIP events on: device time per kernel class without
+    concurrent streams (outside every timed region); the grouping is restored afterwards"""
+    groups = solver.schedule()[0]
+    solver.set_groups(1)
+    solver.set_profile(True)
+    solver.solve(raise_on_error=False)
+    ms = solver.profile()[0]
+    solver.set_groups(groups)
+    return ms
 
 
 def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None, chunk=None, sync=None, counters_as=None):
@@ -220,6 +238,7 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
         dt = time.perf_counter() - t0
         rec = {'dt': dt, 'ev_ref': ev_ref, 'ev_exec': ev_exec, 'nfail': nfail}
     kms, klaunch, algbytes = solver.profile()   # of the last chunk's solve
+    serial_ms = serial_profile(solver)
     solver.close()
     value = rec['ev_exec'] / rec['dt']
     out = {'workload': label or '%s x %d draws' % (workload, ndraw), 'ndraw': ndraw, 'chunk': chunk, 'build_flags': flags,
@@ -228,7 +247,8 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
            'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
            'config': 'T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (desc['T'], desc['ngridm'], desc['ny'], lib.info.nd,
                                                                                    lib.info.nst, desc['a0'], desc['mmax'])}
-    out['roofline'] = roofline_record(counters_as or workload, chunk, kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value)
+    out['roofline'] = roofline_record(counters_as or workload, chunk, kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value,
+                                      serial_ms=serial_ms)
     out['_raw'] = rec
     return out
 
@@ -355,19 +375,20 @@ def main():
     for s in range(args.warmup):
         if solver:
             run_step(s)
-    if solver:
-        solver.set_profile(True)
 
     sync_all()
     t0 = time.perf_counter()
     tot = np.zeros(4, dtype=np.int64)
     for s in range(args.warmup, nsteps_all):
         if solver:
+            if s == nsteps_all - 1:
+                solver.set_profile(True)   # HIP events around the launches of the LAST timed step (egdst_get_profile reports the last solve)
             tot += np.array(run_step(s), dtype=np.int64)
     sync_all()
     dt = time.perf_counter() - t0
 
-    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(4), np.zeros(4, dtype=np.int32), 0)   # of the LAST solve
+    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(9), np.zeros(9, dtype=np.int32), 0)   # of the LAST solve
+    serial_ms = serial_profile(solver) if (solver and rank == 0 and world == 1 and not args.no_extras) else None
     # ---- final objective reduce: the only collective of the path (RCCL over xGMI when world > 1) -----------------
     last = obj[nsteps_all - 1, :mine_n, 0] if mine_n else torch.zeros(0, dtype=torch.float64, device='cuda')
     okmask = ~torch.isnan(last)
@@ -437,7 +458,7 @@ def main():
             'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
             'envelope_cells_by_throughput_path': main_extra['envelope_cells_by_throughput_path'],
             'roofline': roofline_record(args.workload, chunk, kms, klaunch, algbytes, ev_exec_all / args.steps / max(world * nchunks, 1),
-                                        ev_exec_all / dt_max, small=args.small),
+                                        ev_exec_all / dt_max, small=args.small, serial_ms=serial_ms),
         }
         one = host_draws[-1][:1] if mine_n else None
         if not args.no_single_solve and world == 1 and mine_n:

@@ -175,7 +175,7 @@ struct LaneEval {
 // their bracket searches were 2 x 11 dependent L2 round trips per term and made a regeneration ~0.8 ms (profiles/r03_*)
 template <class TT = Tab>
 static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env *E, const ms_pv *cur, int slot1, int draw,
-                                                        double A, const TT *lt = nullptr)
+                                                        double A, const TT *lt = nullptr, int lt_sorted = 0)
 {
     LaneEval r;
     const int ny = b.g.ny;
@@ -213,7 +213,8 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env
             status = -2707;
             break;
         }
-        const int tsorted = b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + nxt.ist] : 0;  // (k_sortcheck ran this period)
+        // the M column is known to be in order: k_sortcheck ran this period, or the caller checked its staged copy
+        const int tsorted = lt ? lt_sorted : (b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + nxt.ist] : 0);
         for (int iy = 0; iy < niy; iy++) {
             double pr1;
             if (niy == 1) {
@@ -278,7 +279,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env
 template <class TT, int GW = WAVE>
 static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_env *E, int slot1, int draw, const ms_pv *cur,
                                           double savings, int keep, double *rhs_o, double *evf_o, int *nev,
-                                          int *brk_ist, double *brk_shock, double *brk_cash, const TT *lt)
+                                          int *brk_ist, double *brk_shock, double *brk_cash, const TT *lt, int lt_sorted = 0)
 {
     const int lane = threadIdx.x & (GW - 1);                          // position in the group
     const int gbase = (threadIdx.x & (WAVE - 1)) - lane;            // first lane of the group within the wave
@@ -311,7 +312,7 @@ static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_e
         }
         if (t.len < 2) return -10;
         if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
-        const int tsorted = b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + ist1] : 0;  // (k_sortcheck ran this period)
+        const int tsorted = lt ? lt_sorted : (b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + ist1] : 0);  // (see eg_lane_eval)
         for (int base = 0; base < niy && status == 0; base += GW) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
@@ -400,6 +401,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
     // expectation of a re-basing stream are LDS reads instead of dependent L2 loads (the row past the end is part of
     // the table: the reference reads it for one-row tables)
     bool staged = false;
+    int staged_sorted = 0;
     TabL ltab;
     ltab.M = ltab.C = ltab.V = nullptr, ltab.TH = ltab.D = nullptr, ltab.len = ltab.thlen = 0;
     if (full && MS_NST == 1) {
@@ -419,6 +421,17 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
             ltab.TH = tg.TH, ltab.D = tg.D, ltab.len = tg.len, ltab.thlen = tg.thlen;
         }
         __syncthreads();
+        if (staged) {   // is the staged M column in order?  then one bracket search serves both interpolations of a term (eg_term)
+            __shared__ int fx_bad;
+            if (threadIdx.x == 0) fx_bad = 0;
+            __syncthreads();
+            int bad = 0;
+            for (int i = threadIdx.x; i + 1 < tg.len; i += NW * WAVE)
+                if (!(fx_tab[i] <= fx_tab[i + 1])) bad = 1;
+            if (bad) fx_bad = 1;  // (benign race: every writer stores 1)
+            __syncthreads();
+            staged_sorted = (tg.len >= 4 && !fx_bad) ? 1 : 0;
+        }
     }
     double fp_last = NAN, fp_M = NAN, kp_M = 0, kp_C = 0, kp_V = 0;  // previous visit of the resend branch; the point kept last
     int fp_ncalls = -2, fp_ngen = -1, fp_np = 0, fp_nev = 0;
@@ -564,7 +577,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                 double An = last;
                 if (can) {
                     An = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, n);
-                    r = (full && staged) ? eg_lane_eval<TabL>(b, &E, &cur, slot1, draw, An, &ltab) : eg_lane_eval<Tab>(b, &E, &cur, slot1, draw, An);
+                    r = (full && staged) ? eg_lane_eval<TabL>(b, &E, &cur, slot1, draw, An, &ltab, staged_sorted) : eg_lane_eval<Tab>(b, &E, &cur, slot1, draw, An);
                 }
                 {   // phase 1: what every wave found, in batch order
                     const unsigned long long canm = __ballot(can);
@@ -695,7 +708,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
         const int nev0 = nev;
         int st;
         if (full && staged)
-            st = eg_wave_expectation<TabL>(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash, &ltab);
+            st = eg_wave_expectation<TabL>(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash, &ltab, staged_sorted);
         else
             st = eg_wave_expectation<Tab>(b, &E, slot1, draw, &cur, last, keep, &rhs, &evf, &nev, &bist, &bshock, &bcash,
                                           (const Tab *)nullptr);
@@ -1830,9 +1843,15 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
                                 zfirst = (z != 0xffff);
                             else if (z == 0xffff)
                                 zfirst = false;
-                            else
-                                zfirst = pt_before(lds_keys ? (double)lkeys[z] : im[z], iv[z], ifn[z], z, lds_keys ? (double)lkeys[a] : im[a], iv[a],
-                                                   ifn[a], a);
+                            else {
+                                // (comp1 by its keys in turn: the M keys sit in LDS, the rest -- V, the function -- is
+                                //  fetched from global memory only when the M keys tie, which is rare)
+                                const double mz = lds_keys ? (double)lkeys[z] : im[z], ma = lds_keys ? (double)lkeys[a] : im[a];
+                                if (mz != ma)
+                                    zfirst = mz < ma;
+                                else
+                                    zfirst = pt_before(mz, iv[z], ifn[z], z, ma, iv[a], ifn[a], a);
+                            }
                             if (((i & k) == 0) == zfirst) lperm[i] = (unsigned short)z, lperm[q] = (unsigned short)a;
                         }
                     }
@@ -2218,6 +2237,7 @@ static_assert(MS_ND <= ENV_SMALLF, "too many discrete choices for the LDS bookke
 
 struct WalkJob {  // what one envelope walk needs besides the sorted stream
     int it, ist, nf, npts, sec_id, ocap, e13, nthrhmax, stackcap, cap;
+    int curcap, slice0;  // entries of cur[] / mark[] (stack: twice as many + 4); slice of them a walking wave gets while nf + 2 fits it
     double sec_ev;
     eg_ldsi *fstart, *dims, *cur, *mark;
     const eg_ldsd *evfa0;
@@ -2331,8 +2351,8 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
     int nseg = 1, thstride = j.nthrhmax, thcap = j.nthrhmax;
     // slice of the cursor arrays per walking wave, and how many waves that leaves room for
-    const int slice = (j.nf + 2 <= ENV_SEGNF_SLICE) ? ENV_SEGNF_SLICE : ((j.nf + 2 + 31) / 32) * 32;
-    const int ww = min(min(ENV_BS / WAVE, ENV_MAXWW), ENV_SMALLF / slice);
+    const int slice = (j.nf + 2 <= j.slice0) ? j.slice0 : ((j.nf + 2 + 31) / 32) * 32;
+    const int ww = min(min(ENV_BS / WAVE, ENV_MAXWW), j.curcap / slice);
 #ifdef EGDST_STAMPS2
     unsigned long long s2_ = wall_clock64();
 #define STAMP2(k) do { __syncthreads(); if (tid_ == 0 && j.dbg) { const unsigned long long n_ = wall_clock64(); atomicAdd((unsigned long long *)j.dbg + (k), n_ - s2_); s2_ = n_; } } while (0)
@@ -2645,6 +2665,7 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
     job.e13 = compact ? EGDST_E_CAPACITY : 13;
     job.nthrhmax = b.g.nthrhmax;
     job.stackcap = 2 * (ENV_SMALLF + 2);
+    job.curcap = ENV_SMALLF, job.slice0 = ENV_SEGNF_SLICE;
     job.cap = (int)W;
     job.fstart = fstart;
     job.dims = fdims;
@@ -3121,10 +3142,20 @@ static_assert(MS_ND <= TP_NF, "TP_NF must hold one function per choice");
     }())
 
 // static LDS of a workgroup of the path, shared by its phases (the fused kernels run them one after the other)
+#ifdef EGDST_EMU
+#define TP_WALK_BS ENV_BS_EMU
+#define TP_SORT_BS ENV_BS_EMU
+#else
+#define TP_WALK_BS 256   // threads of a k_tp_walk workgroup: all load the stream, up to four waves walk segments of it
+#define TP_SORT_BS 512
+#endif
+#define TP_SEG_SLICE 32  // cursor entries per walking wave while nf + 2 <= 32 (run_walk: WalkJob.slice0)
+#define TP_CURCAP 128    // cursor entries in all: four walking waves of 32, two of 64
+static_assert(TP_NF + 2 <= TP_CURCAP, "the cursor arrays must hold one walk of TP_NF functions");
 struct TpShared {
     int sh[ENV_MAXBS + 2];                                   // scan scratch of the block-wide helpers
-    int fstart[TP_NF], fdims[TP_NF], fcur[TP_NF], fmark[TP_NF];
-    int stack[2 * (TP_NF + 2)];
+    int fstart[TP_NF], fdims[TP_NF], fcur[TP_CURCAP], fmark[TP_CURCAP];
+    int stack[2 * (TP_CURCAP + 2)];
     double evfa0[MS_ND];
     int oob, res[3];
 };
@@ -3273,14 +3304,16 @@ __global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp
 // stage 0: the pieces of one folded choice list (secondary envelope); stage 1: the choice lists of a cell (primary).
 // lkcap: M keys that fit the dynamic LDS.
 // bxi: stage 0: cell slot * MS_ND + choice; stage 1: cell slot
-static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int bxi, TpShared *S, double *dynlds)
+// wcap: points the walk of this stage keeps in LDS -- a longer stream (a degenerate guess stream: thousands of repeated
+// points) is k_envelope's, and is not sorted here either
+static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int wcap, int bxi, TpShared *S, double *dynlds)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims;
     double *const s_evfa0 = S->evfa0;
     int &s_oob = S->oob;
     const int bx_ = stage ? bxi : bxi / MS_ND, id = stage ? 0 : bxi % MS_ND;
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, TPB = (int)blockDim.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
     if (TP_DEFERRED_UNIFORM(S, cell)) return;  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
 #ifdef EGDST_TPSTAMPS
@@ -3301,8 +3334,9 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
     if (stage == 0) {
         if (!R->active || R->nfold <= 0) return;
         npts = R->cnt + R->nfold;
+        if (npts > wcap) TP_DEFER();
         nf = id + R->nfold + 1;
-        for (int f = tid; f < nf; f += TP_BS) {
+        for (int f = tid; f < nf; f += TPB) {
             const int a = R->fstart[f], z = (f + 1 < nf) ? R->fstart[f + 1] : npts;
             fstart[f] = (f < id) ? 0 : a;
             fdims[f] = (f < id) ? 0 : z - a;
@@ -3315,6 +3349,9 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
         double *pM = b.pM + wo, *pC = b.pC + wo, *pV = b.pV + wo;
         int *pF = b.pF + wo;
         int any = 0, nall = 0;
+        for (int k = 0; k < MS_ND; k++) nall += (R + k)->cnt;
+        if (nall > wcap) TP_DEFER();
+        nall = 0;
         for (int k = 0; k < MS_ND; k++) {
             const TpRec *Rk = R + k;
             const int cntk = Rk->cnt;
@@ -3322,7 +3359,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
             if (tid == 0) s_fstart[k] = nall, s_fdims[k] = cntk, s_evfa0[k] = Rk->evfa0;
             const size_t src = (size_t)k * b.g.Cp;
             if (k > 0 && cntk > 0 && src != (size_t)nall) {
-                for (int base = 0; base < cntk; base += TP_BS) {  // (chunks: read, barrier, write -- the ranges may overlap)
+                for (int base = 0; base < cntk; base += TPB) {  // (chunks: read, barrier, write -- the ranges may overlap)
                     const int r = base + tid;
                     double a_ = 0, b2_ = 0, c_ = 0;
                     if (r < cntk) a_ = pM[src + r], b2_ = pC[src + r], c_ = pV[src + r];
@@ -3331,7 +3368,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
                     __syncthreads();
                 }
             }
-            for (int r = tid; r < cntk; r += TP_BS) pF[nall + r] = k;
+            for (int r = tid; r < cntk; r += TPB) pF[nall + r] = k;
             nall += cntk;
         }
         if (!any || nall == 0) TP_DEFER();  // (errors 14 and 15 of k_envelope)
@@ -3384,17 +3421,17 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
             b.tpcell[cell].npts = npts, b.tpcell[cell].fused = fused;
     }
 }
-__global__ void __launch_bounds__(TP_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap)
+__global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap, int wcap)
 {
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;
-    tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, (int)blockIdx.x, &S, (double *)dynlds);
+    tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, wcap, (int)blockIdx.x, &S, (double *)dynlds);
 }
 
 // One wave per job.  stage 0: secondary envelope of a folded choice list, result written over the list it came from (dead by
 // then: its pieces live in the s slice, the sorted stream in the q slice); stage 1: primary envelope into the period's table.
 #ifndef TP_WALK_MINW
-#define TP_WALK_MINW 1
+#define TP_WALK_MINW 3  // (at most 168 VGPRs: three 4-wave workgroups per CU, what the LDS of the stream allows anyway; 172 without)
 #endif
 // stage 1 also lists the cells that are left to k_envelope (`list`, `cnt`: this (group, period)'s; every cell's stage-1
 // workgroup runs exactly once, so a cell is listed exactly once whichever kernel flagged it).
@@ -3444,17 +3481,19 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     job.ocap = b.g.Cp;
     job.e13 = compact ? EGDST_E_CAPACITY : 13;
     job.nthrhmax = b.g.nthrhmax;
-    job.stackcap = 2 * (TP_NF + 2);
+    job.stackcap = 2 * (TP_CURCAP + 2);
+    job.curcap = TP_CURCAP, job.slice0 = TP_SEG_SLICE;
     job.fstart = fstart, job.dims = fdims;
     job.cur = (eg_ldsi *)s_fcur, job.mark = (eg_ldsi *)s_fmark;
     job.evfa0 = (const eg_ldsd *)s_evfa0;
     job.stack = (eg_ldsi *)s_stack;
     job.dbg = b.dbg + 16 * draw;
-    job.noseg = 1;
+    job.noseg = b.noseg;
     job.sh = sh;
     job.segstat = b.segstat + 2 * (size_t)draw;
     job.klog = nullptr, job.kcnt = nullptr, job.kcap = 0;
-    job.wM = job.wV = job.wC = nullptr, job.wcap = 0;
+    // scratch rows for the segments of a cut walk: the s arrays -- the unsorted pieces of stage 0, dead once they are sorted
+    job.wM = b.sM + wo, job.wV = b.sV + wo, job.wC = b.sC + wo, job.wcap = stage ? (int)Wcell : b.g.Cp;
     int classified = 0, hw_rows = 0, hw_th = 0;
     unsigned long long evals = 0;
     double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
@@ -3540,7 +3579,7 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     __syncthreads();
     TWST(0);
     int we = 0, wn = 0, wm = 0;
-    run_walk<2, false>(&E, job, Lm, b.qC + wo, Lv, Lf, Lp, Lc, &we, &wn, &wm, classified);
+    run_walk<2, true>(&E, job, Lm, b.qC + wo, Lv, Lf, Lp, Lc, &we, &wn, &wm, classified);
     TWST(1);
     __syncthreads();  // (the results are wave 0's: hand them to the other waves of a fused kernel)
     if (tid == 0) S->res[0] = we, S->res[1] = wn, S->res[2] = wm;
@@ -3575,7 +3614,7 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
         atomicAdd(&b.algbytes[draw], by);
     }
 }
-__global__ void __launch_bounds__(WAVE, TP_WALK_MINW) k_tp_walk(const Batch *bp_, int it, int stage, int *list, int *cnt, int lcap)
+__global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk(const Batch *bp_, int it, int stage, int *list, int *cnt, int lcap)
 {
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;

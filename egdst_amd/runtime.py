@@ -415,11 +415,12 @@ class Solver:
     def set_profile(self, on=True):
         self.lib.check(self.lib.lib.egdst_set_profile(self.h, int(on)))
 
+    PROFILE_CLASSES = ['probe', 'grid', 'k_envelope', 'regeneration', 'tp_prep', 'tp_sort0', 'tp_sort1', 'tp_walk0', 'tp_walk1']
+
     def profile(self):
-        """(ms[4], launches[4], algorithmic bytes) of the last solve: probe/terminal, the grid kernel, the envelope step,
-        regeneration (k_fixup_scan + k_fixup)."""
-        ms = np.zeros(4)
-        ln = np.zeros(4, dtype=np.int32)
+        """(ms[9], launches[9], algorithmic bytes) of the last solve by kernel class (PROFILE_CLASSES; include/egdst.h)."""
+        ms = np.zeros(9)
+        ln = np.zeros(9, dtype=np.int32)
         ab = C.c_longlong(0)
         self.lib.check(self.lib.lib.egdst_get_profile(self.h, _dp(ms), _ip(ln), C.byref(ab)))
         return ms, ln, int(ab.value)

@@ -205,13 +205,16 @@ int egdst_objective_dev(egdst_handle *h, double *out_dev);
 int egdst_get_objective(egdst_handle *h, double *out /* host, [2*ndraw] */);
 
 /* Measurement: with profiling on, the launches of a solve are bracketed by HIP events on the stream they are
- * launched on (the draw groups' streams).  egdst_get_profile returns, for the classes {0: k_probe / k_terminal, 1: the grid
- * kernel (k_grid_lds, k_grid_wide or k_grid) alone, 2: the envelope step (k_envelope, or the kernels of its throughput path),
- * 3: regeneration of guess streams (k_fixup_scan + k_fixup)}, the summed device time in ms and the number of bracketed launches
- * of the LAST solve, and the algorithmic table bytes of that solve summed over draws (24 B per table row read once per
- * period, 24 B per row written, 16 B per threshold). */
+ * launched on (the draw groups' streams).  egdst_get_profile returns, for the nine classes
+ *   0 k_probe / k_terminal      1 the grid kernel alone (k_grid_lds, k_grid_wide or k_grid)      2 k_envelope
+ *   3 regeneration of guess streams (k_fixup_scan + k_fixup)
+ *   4 k_tp_prep   5, 6 k_tp_sort stage 0, 1   7, 8 k_tp_walk stage 0, 1   (the envelope step's throughput path; with it on,
+ *     class 2 is the k_envelope launch for the cells the path left over)
+ * the summed device time in ms and the number of bracketed launches of the LAST solve (kernels of a class that was not
+ * launched: 0), and the algorithmic table bytes of that solve summed over draws (24 B per table row read once per period,
+ * 24 B per row written, 16 B per threshold). */
 int egdst_set_profile(egdst_handle *h, int on);
-int egdst_get_profile(egdst_handle *h, double *ms /* [4] */, int *launches /* [4] */, long long *algbytes);
+int egdst_get_profile(egdst_handle *h, double *ms /* [9] */, int *launches /* [9] */, long long *algbytes);
 
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);

@@ -97,6 +97,44 @@ def test_solution_import_serves_simulator_and_accessor(args):
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
 
 
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('args,env', [
+    (['retirement2', 'T=8, ngridm=200, nthrhmax=200'], {}),                         # walks cut into segments (four walking waves)
+    (['occ3', 'T=6, ngridm=30, ngridmax=100'], {'EGDST_TP_SORT_LKCAP': '16'}),       # sampled key index, permutation through global memory
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # streams beyond the walk's LDS: left to k_envelope
+])
+def test_throughput_path_of_the_envelope_step(args, env):
+    """EGDST_ENV_TP=1: the envelope step as the lean kernels of big batches (k_tp_prep / k_tp_sort / k_tp_walk) with multi-lane
+    waves and multi-wave workgroups -- bit-exact against the oracle, ASan clean, with the LDS regions of every phase separated
+    by poisoned gaps; cells the path does not take go through k_envelope's list pass."""
+    e = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_ENV_TP='1', EMU_WAVE='4',
+             EMU_ENV_BS='16', **env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py')] + args, env=e, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
+    done, left = eval(r.stdout.split('tp done/left')[1].strip())
+    assert done + left > 0 and (done > 0 or 'EGDST_TP_LKCAP' in env), r.stdout
+    if env.get('EGDST_TP_LKCAP'):
+        assert left > 0
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+@pytest.mark.parametrize('args,lds', [(['retirement2', 'T=8, ngridm=60'], ''), (['occ3', 'T=6, ngridm=30, ngridmax=100'], '24')])
+def test_several_asset_points_per_lane_with_neighbour_hinted_search(args, lds):
+    """EGDST_GRID_PPL=1: k_grid_lds_n -- a lane evaluates four consecutive asset points side by side and starts every bracket
+    search at its neighbour's bracket (eg_bracket_near); whole columns in LDS and the sampled index (EGDST_GRID_LDS)."""
+    e = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_GRID_PPL='1', EGDST_GRID_WIDE='0')
+    if lds:
+        e['EGDST_GRID_LDS'] = lds
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py')] + args, env=e, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
 def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
     """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=27): with ping-pong
     tables the failure must be the oracle's (error 15 at it=26), not a success built on stale rows."""
