@@ -13,6 +13,9 @@
 #ifndef EG_WAVE
 #define EG_WAVE 64
 #endif
+#ifndef ENV_SEQ_NF
+#define ENV_SEQ_NF 0  // > 0: walks of at most this many functions take their generic steps on one lane (env_walk_wave; measured slower)
+#endif
 
 // Address spaces are kept in the TYPES: the sorted stream is either LDS- or global-resident (template
 // parameter L, see EgMem), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
@@ -1008,7 +1011,23 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
         }
         if (step_now) {
             e.lastg = lastg;  // rows committed by the batches since the last generic step
-            const bool ok_ = env_step_wave(e, i);
+            bool ok_;
+#if ENV_SEQ_NF > 0
+            // (experiment, off: walks of few functions take the generic step as the reference's own plain loop on ONE lane --
+            //  env_step / env_crossing -- and hand the scalar state to the others.  Measured on C2 x 4096: 6.55 us per step
+            //  against 6.03 us wave-cooperative, and 23 more spilled VGPRs in a kernel that has none to spare: 175 ms against 170.)
+            if (e.nf <= ENV_SEQ_NF) {
+                EG_WSYNC();  // (the rebuilt cursors are in place)
+                int okl = 1;
+                if (lane == 0) okl = env_step(e, i) ? 1 : 0;
+                EG_WSYNC();
+                ok_ = __shfl(okl, 0) != 0;
+                e.oi = __shfl(e.oi, 0), e.oj = __shfl(e.oj, 0), e.ci = __shfl(e.ci, 0), e.pm = __shfl(e.pm, 0);
+                e.err = __shfl(e.err, 0);
+                e.lastg = __shfl(e.lastg, 0);
+            } else
+#endif
+                ok_ = env_step_wave(e, i);
             lastg = e.lastg;
             pm = e.pm;
             if (!ok_) return;

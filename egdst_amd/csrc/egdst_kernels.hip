@@ -2098,6 +2098,8 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
                 int rc_ = 0;
                 for (int j = 0; j < npts; j++)
                     if (pt_before(Km[j], Kv[j], ifn[j], j, Km[i], Kv[i], ifn[i], i)) rc_++;
+                if (dbg) atomicAdd(&dbg[12], 1);                     // ranks checked / ranks that differ: debug words 12 / 13 of the draw
+                if (rc_ != r[k] && dbg) atomicAdd(&dbg[13], 1);
                 if (rc_ != r[k] && atomicAdd(&g_rankchk, 1) < 6)
                     printf("rankchk i=%d k=%d n=%d r=%d count=%d f=%d npts=%d nf=%d tid=%d\n", i, k, n, r[k], rc_, f[k], npts, nf,
                            (int)threadIdx.x);
@@ -3305,7 +3307,7 @@ __global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp
 // lkcap: M keys that fit the dynamic LDS.
 // bxi: stage 0: cell slot * MS_ND + choice; stage 1: cell slot
 // wcap: points the walk of this stage keeps in LDS -- a longer stream (a degenerate guess stream: thousands of repeated
-// points) is k_envelope's, and is not sorted here either
+// points) is k_envelope's, and is not sorted here either; 0: no limit (the walks run on global memory, k_tp_walk_g)
 static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int wcap, int bxi, TpShared *S, double *dynlds)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims;
@@ -3334,7 +3336,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
     if (stage == 0) {
         if (!R->active || R->nfold <= 0) return;
         npts = R->cnt + R->nfold;
-        if (npts > wcap) TP_DEFER();
+        if (wcap > 0 && npts > wcap) TP_DEFER();
         nf = id + R->nfold + 1;
         for (int f = tid; f < nf; f += TPB) {
             const int a = R->fstart[f], z = (f + 1 < nf) ? R->fstart[f + 1] : npts;
@@ -3350,7 +3352,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
         int *pF = b.pF + wo;
         int any = 0, nall = 0;
         for (int k = 0; k < MS_ND; k++) nall += (R + k)->cnt;
-        if (nall > wcap) TP_DEFER();
+        if (wcap > 0 && nall > wcap) TP_DEFER();
         nall = 0;
         for (int k = 0; k < MS_ND; k++) {
             const TpRec *Rk = R + k;
@@ -3446,6 +3448,10 @@ __global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batc
     } while (0)
 // dynlds: the sorted stream: lcap entries of M, V (8 B), class word (4 B), function id and position list (2 B).  Any number
 // of waves: all of them load the stream and classify where the sort did not, wave 0 walks.
+// GLOBAL: the stream stays in global memory (long streams: C5's 65 536 points, C3's 12 000): the walk k_envelope runs on such
+// streams, but as a kernel of its own -- a few KB of LDS and 168 VGPRs, so that several cells share a CU where k_envelope, sized
+// for its LDS-resident streams, takes a CU per cell.
+template <bool GLOBAL>
 static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, int *list, int *cnt, int lcap, int bxi, TpShared *S, double *dynlds)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims, *const s_fcur = S->fcur, *const s_fmark = S->fmark;
@@ -3538,6 +3544,11 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     // over global memory took 230-440 us per launch (profiles/r03_*), nearly all of it in four or five such events.  The
     // consumption column stays where it is: the walk copies it to the rows it keeps and reads it at a kink only.
     // A stream that does not fit (a degenerate guess stream with thousands of points) is k_envelope's.
+    int we = 0, wn = 0, wm = 0;
+    if (GLOBAL) {
+        TWST(0);
+        run_walk<0, true>(&E, job, b.qM + wo, b.qC + wo, b.qV + wo, b.qF + wo, b.rank + wo, b.gcls + wo, &we, &wn, &wm, classified);
+    } else {
     if (job.npts > lcap || job.npts >= 65536) {
         if (stage == 1) TP_DEFER_LISTED();
         TP_DEFER();
@@ -3578,8 +3589,8 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     }
     __syncthreads();
     TWST(0);
-    int we = 0, wn = 0, wm = 0;
     run_walk<2, true>(&E, job, Lm, b.qC + wo, Lv, Lf, Lp, Lc, &we, &wn, &wm, classified);
+    }
     TWST(1);
     __syncthreads();  // (the results are wave 0's: hand them to the other waves of a fused kernel)
     if (tid == 0) S->res[0] = we, S->res[1] = wn, S->res[2] = wm;
@@ -3618,7 +3629,17 @@ __global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk(const Batc
 {
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;
-    tp_walk(EG_BATCH_REF(bp_), it, stage, list, cnt, lcap, (int)blockIdx.x, &S, (double *)dynlds);
+    tp_walk<false>(EG_BATCH_REF(bp_), it, stage, list, cnt, lcap, (int)blockIdx.x, &S, (double *)dynlds);
+}
+#ifdef EGDST_EMU
+#define TP_WALKG_BS ENV_BS_EMU
+#else
+#define TP_WALKG_BS 512  // eight walking waves for the long streams
+#endif
+__global__ void __launch_bounds__(TP_WALKG_BS, TP_WALK_MINW) k_tp_walk_g(const Batch *bp_, int it, int stage, int *list, int *cnt)
+{
+    __shared__ TpShared S;
+    tp_walk<true>(EG_BATCH_REF(bp_), it, stage, list, cnt, 0, (int)blockIdx.x, &S, nullptr);
 }
 
 // (Measured and not kept: the same phases FUSED into two kernels -- per (cell, choice) the list, its sort and its secondary

@@ -17,6 +17,14 @@
  * eg_exp/eg_log/eg_pow == glibc exp/log/pow bit for bit (tests/test_math_vs_libm.py: 0 ulp over 10^7 arguments
  * per function, special values included), hence GPU == portable oracle == glibc oracle.
  *
+ * PROVENANCE AND LICENCE: the algorithm and the constants are those of the exp / log / pow of ARM optimized-routines
+ * (Szabolcs Nagy; "MIT OR Apache-2.0 WITH LLVM-exception"), which glibc imported in 2.28 and distributes under the LGPL 2.1+.
+ * Nothing of either code base is copied here: the functions below are written from the published algorithm and checked
+ * against the behaviour of the installed libm, and the tables in egdst_math_tables.h are numeric data extracted by
+ * tools/make_math_tables.py from the libm-2.35.a of this image (the same numbers optimized-routines publishes in
+ * math/exp_data.c, log_data.c, pow_log_data.c).  A distributor who wants no question about the LGPL can regenerate the tables
+ * from the MIT-licensed optimized-routines sources instead: the values are identical.
+ *
  * Selection: models are generated with MS_EXP/MS_LOG/MS_POW; defining EGDST_NATIVE_MATH maps them to the
  * platform libm instead (the oracle's second build, which checks the claim above at full problem sizes).
  */

@@ -264,15 +264,18 @@ TP_CASES = {
 
 
 @pytest.mark.parametrize('name', sorted(TP_CASES))
-@pytest.mark.parametrize('keys', ['lds_keys', 'sampled_keys'])
+@pytest.mark.parametrize('keys', ['lds_keys', 'sampled_keys', 'global_walk'])
 def test_throughput_envelope_path_bit_exact(name, keys, monkeypatch):
     """The envelope step of big batches runs as five lean kernels with one wave per walk (k_tp_prep / k_tp_sort / k_tp_walk,
     egdst_kernels.hip) and hands the cells it does not take to k_envelope.  Forced on here for single solves (EGDST_ENV_TP=1):
     tables, thresholds and evaluation counts equal the oracle's bit for bit, with the sort's M keys whole in LDS and with so
-    little LDS that it works on a sampled index of them; and the path really does the cells (egdst_get_tp_stats)."""
+    little LDS that it works on a sampled index of them; with the walks over global memory, as for streams too long for LDS
+    (k_tp_walk_g, EGDST_TP_LONG); and the path really does the cells (egdst_get_tp_stats)."""
     monkeypatch.setenv('EGDST_ENV_TP', '1')
-    if keys == 'sampled_keys':
+    if keys != 'lds_keys':
         monkeypatch.setenv('EGDST_TP_SORT_LKCAP', '96')
+    if keys == 'global_walk':
+        monkeypatch.setenv('EGDST_TP_LONG', '2')
     m = TP_CASES[name]()
     s = gpu_solve(m)
     sol = s.solution(0)
@@ -700,3 +703,23 @@ def test_segmented_envelope_walks_are_used_and_exact(monkeypatch):
             else:
                 assert merged >= sol.nt // 2 and fallback <= merged // 4, (name, merged, fallback)
             s.close()
+
+
+@pytest.mark.parametrize('tp', ['0', '1'])
+def test_every_rank_of_the_sort_equals_a_plain_count(tp, monkeypatch):
+    """The checking build of the sort (-DEGDST_RANKCHK): every rank the merge-path / counting sort of the envelope step
+    assigns (blk_rank_sort: comp1 order of egdst_solver.c:1570-1582 extended by the input index) is compared on the device
+    with a plain count over the whole stream -- on C2 at full size, through k_envelope and through the throughput path:
+    millions of ranks checked, none differs, and the solution is still the oracle's."""
+    monkeypatch.setenv('EGDST_ENV_TP', tp)
+    m = workloads.c2()[0]
+    lib = build.build_model(m, extra_flags=['-DEGDST_RANKCHK'])
+    s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
+    s.set_params(m.param_vector()[None])
+    assert s.solve(raise_on_error=False) == 0
+    dbg = s.debug(0)
+    assert dbg[12] > 100000 and dbg[13] == 0, dbg.tolist()
+    ref = Oracle(m).solve()
+    ok, rep = compare(s.solution(0), ref, rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    s.close()

@@ -102,6 +102,7 @@ def test_solution_import_serves_simulator_and_accessor(args):
     (['retirement2', 'T=8, ngridm=200, nthrhmax=200'], {}),                         # walks cut into segments (four walking waves)
     (['occ3', 'T=6, ngridm=30, ngridmax=100'], {'EGDST_TP_SORT_LKCAP': '16'}),       # sampled key index, permutation through global memory
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # streams beyond the walk's LDS: left to k_envelope
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LONG': '2', 'EGDST_TP_SORT_LKCAP': '16'}),  # walks over global memory (k_tp_walk_g)
 ])
 def test_throughput_path_of_the_envelope_step(args, env):
     """EGDST_ENV_TP=1: the envelope step as the lean kernels of big batches (k_tp_prep / k_tp_sort / k_tp_walk) with multi-lane
