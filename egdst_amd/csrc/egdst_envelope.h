@@ -13,9 +13,6 @@
 #ifndef EG_WAVE
 #define EG_WAVE 64
 #endif
-#ifndef ENV_SEQ_NF
-#define ENV_SEQ_NF 0  // > 0: walks of at most this many functions take their generic steps on one lane (env_walk_wave; measured slower)
-#endif
 
 // Address spaces are kept in the TYPES: the sorted stream is either LDS- or global-resident (template
 // parameter L, see EgMem), the small per-function arrays and evf(a0) are always LDS.  Generic (flat) pointers into LDS are
@@ -71,6 +68,7 @@ template <int L> struct EnvCtxT {
     int *kcnt;      // -- (choice whose secondary envelope runs or -1, threshold, consumption left, right); nullptr: off
     int kcap;
     int later;      // 1: this context walks a LATER SEGMENT of the stream (run_walk): rows and thresholds exist before it
+    int iend;       // first sorted position the walk did not consume (env_walk_wave)
     int err;
 };
 
@@ -790,6 +788,455 @@ template <int L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L>
     return true;
 }
 
+// ---- generic step with the functions' state on the lanes -------------------------------------------------
+// env_step_wave reaches every segment it evaluates through a chain of LDS reads (cursor -> start of the function's position
+// list -> sorted position -> point), five or six times per step, one after the other: a step took 5-6 us (profiles/r03_*),
+// nearly all of it waiting.  Here lane j loads the state of function j ONCE per step -- cursor, the two points of its current
+// segment, its value at a0 -- and everything the step needs afterwards is a lane read (v_readlane with a uniform index) or the
+// lane's own registers: the "which function is highest" loops are one ballot, the crossing reads its eight numbers from two
+// lanes, the marks of thresholds() are a 64-bit mask.  Same control flow and the same arithmetic per function as
+// env_step_wave (which stays for walks of more than a wave's worth of functions, and for any step whose lane state is not
+// clean -- the guards of env_at); the CPU harness and the parity tests compare the two bit for bit (-DENV_LANE_STEP=0).
+#ifndef ENV_LANE_STEP
+#define ENV_LANE_STEP 1
+#endif
+// Which walks take it: those of the throughput path (L == 2) always; k_envelope's LDS-resident streams (L == 1) when the kernel
+// has its full register budget -- the build for big batches (-DENV_MINW=3, 168 VGPRs) spills 569 VGPRs with it against 222
+// without, and its leftover cells took twice as long (bench leg c2_a0_minus5_batch: 448 ms against 357); streams in global
+// memory (L == 0) never: the lanes load the segments of ALL functions at every step, dozens of scattered reads for the long
+// lists of C5 where env_step_wave touches the two or three functions it needs (C5 x 128: k_envelope 1.98 s against 1.76 s).
+#ifndef ENV_LANE_STEP_ENV
+#if defined(ENV_MINW) && ENV_MINW >= 3
+#define ENV_LANE_STEP_ENV 0
+#else
+#define ENV_LANE_STEP_ENV 1
+#endif
+#endif
+#define ENV_LANES(L) (ENV_LANE_STEP && ((L) == 2 || ((L) == 1 && ENV_LANE_STEP_ENV)))
+// Vector memory operations retire in order and share one counter (loads and stores alike, gfx9): where a register that a
+// global load of the generic step wrote MAY still be pending, the compiler waits for the counter to reach zero before the
+// register is written again -- and found such a place in every regular batch, which then waited for the row stores of the batch
+// before it (a microsecond under load, for a loop iteration of a few hundred cycles).  An explicit wait after every generic step
+// (15 per cell instead of 63) leaves the regular batches with nothing pending but their own stores, which nobody waits for.
+#ifdef EGDST_EMU
+#define EG_VM_DRAIN() ((void)0)
+#else
+#define EG_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0), nothing else
+#endif
+#ifndef ENV_CDEFER_ON
+#define ENV_CDEFER_ON 1  // walks with the consumption column in global memory copy it to the kept rows after the walk (env_walk_wave)
+#endif
+#define ENV_CDEFER(L) ((L) == 2 && ENV_CDEFER_ON)
+#ifdef EGDST_EMU
+#define EG_RLI(v, l) __shfl((int)(v), (l))
+#define EG_RLD(v, l) __shfl((double)(v), (l))
+#else
+static __device__ __forceinline__ int eg_rli_(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+static __device__ __forceinline__ double eg_rld_(double v, int l)
+{
+    const int sl = __builtin_amdgcn_readfirstlane(l);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), sl), __builtin_amdgcn_readlane(__double2loint(v), sl));
+}
+#define EG_RLI(v, l) eg_rli_((v), (l))
+#define EG_RLD(v, l) eg_rld_((v), (l))
+#endif
+
+struct EnvLaneFn {  // function `lane` at a generic step
+    int cur, dim;        // e.cur[lane], e.dims[lane]
+    int pa, pb;          // sorted positions of its points cur and cur + 1 (the current segment; pa only when cur >= 0)
+    double ga, gb, va, vb;
+    double ca, cb;       // consumption at the two points (loaded with the rest: the column may live in global memory, and the loads
+                         // are long done when a kink or a kept row needs them)
+    double evf;          // env_evf(e, lane)
+};
+
+static __device__ __forceinline__ double env_seg_regs(double ga, double gb, double fa, double fb, double x)  // env_seg
+{
+    if (x == ga) return fa;
+    if (x < ga) return -INFINITY;
+    if (x > gb) return -INFINITY;
+    return fb * (x - ga) / (gb - ga) + fa * (gb - x) / (gb - ga);
+}
+template <int L> static __device__ __forceinline__ double env_analytic_ev(const EnvCtxT<L> &e, int f, double x, double ev)  // env_analytic
+{
+    ms_pv cv;
+    cv.it = e.it;
+    cv.ist = e.ist;
+    cv.id = f;
+    cv.cash = cv.savings = cv.shock = 0;
+    return ms_utility(e.E, &cv, x - e.E->a0) + ms_discount(e.E, &cv) * ev;
+}
+// env_fn of the lane's own function
+template <int L> static __device__ __forceinline__ double env_fn_own(const EnvCtxT<L> &e, const EnvLaneFn &F, int lane, double x)
+{
+    if (F.cur >= 0) return env_seg_regs(F.ga, F.gb, F.va, F.vb, x);
+    if (F.evf == -INFINITY) return -INFINITY;
+    return env_analytic_ev(e, lane, x, F.evf);
+}
+// env_fn of function j (uniform), on every lane
+template <int L> static __device__ __forceinline__ double env_fn_of(const EnvCtxT<L> &e, const EnvLaneFn &F, int j, double x)
+{
+    if (EG_RLI(F.cur, j) >= 0) return env_seg_regs(EG_RLD(F.ga, j), EG_RLD(F.gb, j), EG_RLD(F.va, j), EG_RLD(F.vb, j), x);
+    const double ev = EG_RLD(F.evf, j);
+    if (ev == -INFINITY) return -INFINITY;
+    return env_analytic_ev(e, j, x, ev);
+}
+// env_policy of function j (uniform)
+template <int L> static __device__ __forceinline__ double env_policy_of(const EnvCtxT<L> &e, const EnvLaneFn &F, int j, double x)
+{
+    if (EG_RLI(F.cur, j) >= 0) {
+        return env_seg_regs(EG_RLD(F.ga, j), EG_RLD(F.gb, j), EG_RLD(F.ca, j), EG_RLD(F.cb, j), x);
+    }
+    if (EG_RLD(F.evf, j) == -INFINITY) return EG_ZEROC;
+    return x - e.E->a0;
+}
+// env_wave_pick: over the functions whose bit is clear in `skip`: first != 0: the smallest j with thr < value_j(x);
+// first == 0: the j of the largest value_j(x) > thr, smallest index among equals.  Returns j (or -1), its value in *val.
+template <int L>
+static __device__ __forceinline__ int env_lane_pick(const EnvCtxT<L> &e, const EnvLaneFn &F, int lane, double x, double thr,
+                                                    unsigned long long skip, int first, double *val)
+{
+    double t = 0;
+    bool cand = false;
+    if (lane < e.nf && !((skip >> lane) & 1ull)) {
+        t = env_fn_own(e, F, lane, x);
+        cand = thr < t;
+    }
+    unsigned long long mk = __ballot(cand);
+    if (!mk) return -1;
+    int bj = __ffsll((long long)mk) - 1;
+    double bv = EG_RLD(t, bj);
+    if (!first) {
+        mk &= mk - 1ull;
+        while (mk) {  // ascending j: an equal value keeps the earlier index
+            const int j = __ffsll((long long)mk) - 1;
+            mk &= mk - 1ull;
+            const double tj = EG_RLD(t, j);
+            if (tj > bv) bv = tj, bj = j;
+        }
+    }
+    *val = bv;
+    return bj;
+}
+
+// brsolve (env_bisect) between the analytic value of function fa (value at a0: ev) and a segment held in registers
+template <int L>
+static __device__ __forceinline__ void env_bisect_regs(EnvCtxT<L> &e, double *b0, double *b1, double ga, double gb, double va, double vb,
+                                                       int fa, double ev)
+{
+    double bq[3] = {*b0, *b1, 0.0}, a[3], d[3];
+    int have = 0;
+    for (;;) {
+        for (int q = have; q < 2; q++) {
+            a[q] = env_analytic_ev(e, fa, bq[q], ev);
+            d[q] = a[q] - env_seg_regs(ga, gb, va, vb, bq[q]);
+        }
+        have = 2;
+        const double s0 = env_sgn(d[0]), s1 = env_sgn(d[1]);
+        if (s0 == s1) {
+            e.err = 22;
+            return;
+        }
+        if (bq[0] > bq[1]) {
+            e.err = 23;
+            return;
+        }
+        if (fabs(bq[0] - bq[1]) < 2 * EG_DPD || fabs(a[0] - a[1]) < EG_DPD) {
+            *b0 = (bq[0] + bq[1]) / 2;
+            *b1 = bq[1];
+            return;
+        }
+        bq[2] = (bq[0] + bq[1]) / 2;
+        a[2] = env_analytic_ev(e, fa, bq[2], ev);
+        d[2] = a[2] - env_seg_regs(ga, gb, va, vb, bq[2]);
+        const double sm = env_sgn(d[2]);
+        if (s0 == sm)
+            bq[0] = bq[2], a[0] = a[2], d[0] = d[2];
+        else if (s1 == sm)
+            bq[1] = bq[2], a[1] = a[2], d[1] = d[2];
+        else {
+            *b0 = bq[0];
+            *b1 = bq[1];
+            return;
+        }
+    }
+}
+
+// thresholds (env_crossing_wave).  The pair being worked on stays in registers; the stack in LDS holds only the pairs a
+// split leaves for later (the reference's recursion, :1827-1845: (pri, best) is done before (best, nwi)).
+template <int L>
+static __device__ __forceinline__ void env_crossing_lanes(EnvCtxT<L> &e, const EnvLaneFn &F, int lane, unsigned long long marked, int pri,
+                                                          int nwi, int mode)
+{
+    const double a0 = e.E->a0;
+    int sp = 0;  // pairs on the LDS stack
+    while (!e.err) {
+        marked |= (1ull << pri) | (1ull << nwi);
+        const int cp = EG_RLI(F.cur, pri), cn = EG_RLI(F.cur, nwi);
+        double x = 0, top = 0;
+        if ((cp == -1) != (cn == -1)) {  // exactly one of the two is still in its analytic region (:1648-1688)
+            const int ana = (cp == -1) ? pri : nwi, lin = (cp == -1) ? nwi : pri;
+            const double lga = EG_RLD(F.ga, lin), lgb = EG_RLD(F.gb, lin), lva = EG_RLD(F.va, lin), lvb = EG_RLD(F.vb, lin);
+            const double ev = EG_RLD(F.evf, ana), am0 = EG_RLD(F.gb, ana);  // (cursor -1: the lane's second point is the function's first)
+            if (ev == -INFINITY)
+                x = am0;
+            else {
+                double br0 = lga;
+                double br1 = MS_MIN(am0, lgb);
+                env_bisect_regs(e, &br0, &br1, lga, lgb, lva, lvb, ana, ev);
+                if (e.err) return;
+                x = br0;
+            }
+            top = env_seg_regs(lga, lgb, lva, lvb, x);
+        } else if (cp == -1 && cn == -1) {
+            e.err = 21;
+            return;
+        } else {
+            const double p0m = EG_RLD(F.ga, pri), p1m = EG_RLD(F.gb, pri), p0v = EG_RLD(F.va, pri), p1v = EG_RLD(F.vb, pri);
+            const double n0m = EG_RLD(F.ga, nwi), n1m = EG_RLD(F.gb, nwi), n0v = EG_RLD(F.va, nwi), n1v = EG_RLD(F.vb, nwi);
+            const double icn = (n0v * n1m - n1v * n0m) / (n1m - n0m);  // intercepts
+            const double icp = (p0v * p1m - p1v * p0m) / (p1m - p0m);
+            if (p1m == p0m) {  // previous max is vertical
+                x = p0m;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else if (n1m == n0m) {  // entering function is vertical
+                x = n0m;
+                top = (x * (p1v - p0v) / (p1m - p0m)) + icp;
+            } else if (((n1v - n0v) / (n1m - n0m)) == ((p1v - p0v) / (p1m - p0m))) {  // identical slopes
+                x = (p0m + p1m + n0m + n1m) / 4;
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            } else {
+                x = (icp - icn) / (((n1v - n0v) / (n1m - n0m)) - ((p1v - p0v) / (p1m - p0m)));
+                top = (x * (n1v - n0v) / (n1m - n0m)) + icn;
+            }
+        }
+        const int best = env_lane_pick(e, F, lane, x, top, marked, mode == 0, &top);
+        if (best != -1) {  // a third function is higher at the crossing: split (:1827-1845)
+            if (2 * (sp + 2) > e.stackcap) {
+                e.err = 2703;
+                return;
+            }
+            if (mode != 0) {
+                if (lane == 0) e.stack[2 * sp] = best, e.stack[2 * sp + 1] = nwi;
+                sp++;
+            }
+            nwi = best;  // (pri, best) next
+            continue;
+        }
+        const double pol0 = env_policy_of(e, F, pri, x), pol1 = env_policy_of(e, F, nwi, x);
+        double gx = x;  // grid value of the row written last (kept for the duplicate test)
+        if (lane == 0) {
+            e.og[e.oi] = x;
+            e.ov[e.oi] = top;
+            e.oc[e.oi] = (pol0 + pol1) / 2;
+            env_log_kink(e, x, pol0, pol1);
+            e.oth[e.oj] = x;
+            e.oix[e.oj] = nwi;
+        }
+        e.pm = nwi;
+        e.oi += 1;
+        e.oj += 1;
+        if (e.oi >= e.ocap) {
+            e.err = e.e13;
+            return;
+        }
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return;
+        }
+        if (EG_RLD(F.evf, nwi) == -INFINITY && EG_RLI(F.cur, nwi) == -1) {  // :1892-1900
+            gx = x - EG_TOL;
+            if (lane == 0) {
+                e.oc[e.oi - 1] = pol0;
+                e.og[e.oi - 1] = gx;
+            }
+        } else if (EG_DPD > 0) {  // double point at the kink, :1902-1913
+            gx = x + EG_DPD;
+            if (lane == 0) {
+                e.oc[e.oi - 1] = pol0;
+                e.og[e.oi] = gx;
+                e.ov[e.oi] = top;
+                e.oc[e.oi] = pol1;
+            }
+            e.oi += 1;
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
+                return;
+            }
+        }
+        e.lastg = gx;
+        if (sp == 0) return;
+        EG_WSYNC();  // (lane 0's pushes are in place)
+        sp--;
+        pri = e.stack[2 * sp], nwi = e.stack[2 * sp + 1];
+        EG_WSYNC();  // (read before the slot is pushed again)
+    }
+}
+
+// OLDOK: env_step_wave may be called for a step whose lane state is not clean (false: such a step is error 2701, which the
+// throughput path answers by leaving the cell to k_envelope)
+template <int L, bool OLDOK> static __device__ __forceinline__ bool env_step_lanes(EnvCtxT<L> &e, int i)
+{
+    const int lane = threadIdx.x & (EG_WAVE - 1);
+    const double a0 = e.E->a0, bound = e.bound;
+    EG_WSYNC();  // cursors written by the previous step / the rebuild are in place
+    // ---- the lane's function ----------------------------------------------------------------------------------------
+    EnvLaneFn F;
+    F.cur = -1, F.dim = 0, F.pa = F.pb = 0, F.ga = F.gb = F.va = F.vb = F.ca = F.cb = 0, F.evf = -INFINITY;
+    bool clean = true;
+    if (lane < e.nf) {
+        F.dim = e.dims[lane];
+        if (F.dim > 0) {
+            F.cur = e.cur[lane];
+            F.evf = env_evf(e, lane);
+            const int o = e.fstart[lane] + F.cur;
+            clean = F.cur >= -1 && F.cur + 1 < F.dim && o + 1 >= 0 && o + 1 < e.cap && (F.cur < 0 || o >= 0);
+            if (clean) {
+                F.pb = e.rank[o + 1];
+                if (F.cur >= 0) F.pa = e.rank[o];
+                clean = F.pb >= 0 && F.pb < e.npts && F.pa >= 0 && F.pa < e.npts;
+                if (clean) {
+                    F.gb = e.m[F.pb], F.vb = e.v[F.pb], F.cb = e.c[F.pb];
+                    if (F.cur >= 0) F.ga = e.m[F.pa], F.va = e.v[F.pa], F.ca = e.c[F.pa];
+                }
+            }
+        }
+    }
+    if (__ballot(!clean)) {  // (never expected: env_at's guards)
+        if (OLDOK) return env_step_wave(e, i);
+        e.err = 2701;
+        return false;
+    }
+    const int f = e.f[i];
+    const double x = e.m[i];
+    if (f < 0 || f >= e.nf || EG_RLI(F.dim, f < 0 || f >= e.nf ? 0 : f) <= 0) {  // sorted stream inconsistent with the per-function lists
+        if (e.dbg && atomicCAS(&e.dbg[0], 0, 2708) == 0)
+            e.dbg[1] = f, e.dbg[2] = i, e.dbg[3] = e.npts, e.dbg[4] = e.nf, e.dbg[5] = e.sec_id, e.dbg[6] = e.ist;
+        e.err = 2708;
+        return false;
+    }
+    const int curf = EG_RLI(F.cur, f);
+    if ((e.oi > 0 || e.later) && e.lastg == x) {  // duplicate grid point (:1290-1298)
+        if (lane == 0) e.cur[f] = curf + 1;
+        return true;
+    }
+    double fv = EG_RLD(F.vb, f);          // e.v[self], self = env_at(e, f, curf + 1)
+    const double cself = EG_RLD(F.cb, f);  // consumption at that point
+    const unsigned long long absent = __ballot(lane >= e.nf || F.dim <= 0);  // functions without points
+    if (e.oj == 0 && !e.later) {  // first point of the common grid (:1303-1347)
+        // the highest function at x, own value included, smallest index among equals
+        double t = fv;
+        {
+            double tj = 0;
+            bool cand = false;
+            if (!((absent >> lane) & 1ull)) {
+                tj = (lane == f) ? fv : env_fn_own(e, F, lane, x);
+                cand = !(tj != tj);  // (a NaN never wins; a NaN own value never loses: handled below)
+            }
+            unsigned long long mk = __ballot(cand);
+            int bj = -1;
+            double bv = 0;
+            while (mk) {
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                const double v_ = EG_RLD(tj, j);
+                if (bj < 0 || v_ > bv) bv = v_, bj = j;
+            }
+            if (fv != fv)
+                e.ci = f;  // every comparison with NaN is false: nothing replaces the own point
+            else
+                t = bv, e.ci = bj;
+        }
+        if (lane == 0) {
+            e.oth[e.oj] = a0;
+            e.oix[e.oj] = e.ci;
+        }
+        e.pm = e.ci;
+        e.oj++;
+        if (e.oj >= e.nthrhmax) {
+            e.err = 20;
+            return false;
+        }
+        if (e.ci == f) {
+            env_push_wave(e, x, t, cself, lane);
+            if (e.oi >= e.ocap) {
+                e.err = e.e13;
+                return false;
+            }
+        }
+    } else {
+        int xa = -1, xb = -1, xmode = 0, post = 0;  // post: 0 nothing, 1 last row of ci, 2 push own point, 3 last row of cj
+        int cj = -1;
+        if (e.pm == f) {  // point of the current max function
+            double t = 0;
+            const int j = env_lane_pick(e, F, lane, x, fv, absent | (1ull << f), x != bound, &t);
+            if (j < 0) {
+                env_push_wave(e, x, fv, cself, lane);
+                if (e.oi == e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (x != bound) {
+                xa = f, xb = j, xmode = 0, post = 0;
+            } else {
+                fv = t;
+                e.ci = j;
+                xa = f, xb = e.ci, xmode = 1, post = 1;
+            }
+        } else {  // point of another function
+            e.ci = e.pm;
+            const double t = env_fn_of(e, F, e.ci, x);
+            if (t < fv) {
+                double tv = 0;
+                cj = env_lane_pick(e, F, lane, x, fv, absent | (1ull << f) | (1ull << e.ci), 0, &tv);
+                if (cj == -1)
+                    xa = e.ci, xb = f, xmode = 1, post = 2;
+                else {
+                    fv = tv;
+                    xa = e.ci, xb = cj, xmode = 1, post = (x == bound) ? 3 : 0;
+                }
+            } else if (x == bound) {
+                const double vv = env_fn_of(e, F, e.ci, x), pp = env_policy_of(e, F, e.ci, x);
+                env_push_wave(e, x, vv, pp, lane);
+            }
+        }
+        if (xa >= 0) {
+            env_crossing_lanes(e, F, lane, absent, xa, xb, xmode);
+            if (e.err) return false;
+            if (post == 1) {
+                e.lastg = x;
+                const double vv = env_fn_of(e, F, e.ci, x);
+                // (:1406-1408; the reference indexes evfa0 with the exhausted loop variable there)
+                double pp = x - a0;
+                if (EG_RLI(F.cur, e.ci) >= 0)
+                    pp = env_seg_regs(EG_RLD(F.ga, e.ci), EG_RLD(F.gb, e.ci), EG_RLD(F.ca, e.ci), EG_RLD(F.cb, e.ci), x);
+                if (lane == 0) {
+                    e.og[e.oi] = x;
+                    e.ov[e.oi] = vv;
+                    e.oc[e.oi] = pp;
+                }
+                e.oi++;
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (post == 2) {
+                env_push_wave(e, x, fv, cself, lane);
+                if (e.oi >= e.ocap) {
+                    e.err = e.e13;
+                    return false;
+                }
+            } else if (post == 3) {
+                const double vv = env_fn_of(e, F, cj, x), pp = env_policy_of(e, F, cj, x);
+                env_push_wave(e, x, vv, pp, lane);
+            }
+        }
+    }
+    const int dimf = EG_RLI(F.dim, f);  // (a collective: outside the branch)
+    if (lane == 0) e.cur[f] = MS_MIN(curf + 1, dimf - 2);
+    return true;
+}
+
 #ifdef EGDST_SEQ_WALK
 // Plain sequential walk (diagnostic build only).
 template <int L> static __device__ __forceinline__ void env_walk(EnvCtxT<L> &e, int npts)
@@ -897,7 +1344,15 @@ static __device__ __forceinline__ void env_preclass(EnvCtxT<L> &e, int npts, typ
 // state.  later == 1: a later segment (run_walk): starts in the regular phase with the current max function pm0 and the
 // last output grid value lastg0 that the preceding segment is PREDICTED to end with; rows and thresholds are counted
 // from 0 in this segment's own output region.  On return e.pm / e.lastg hold the state after position p1-1.
-template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, int p0 = 0, int p1 = -1, int later = 0,
+// OLDSTEP: env_step_wave is compiled in (not for the walks of the throughput path, L == 2, whose callers keep to a wave's worth
+// of functions: the kernel is 167 VGPRs of mostly dead code otherwise)
+#if defined(EGDST_EMU) || !ENV_LANE_STEP
+#define ENV_OLDSTEP(L) true
+#else
+#define ENV_OLDSTEP(L) ((L) != 2)
+#endif
+template <int L, bool OLDSTEP = ENV_OLDSTEP(L)>
+static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, int p0 = 0, int p1 = -1, int later = 0,
                                                                        int pm0 = -1, double lastg0 = 0)
 {
     const int lane = threadIdx.x & (EG_WAVE - 1);
@@ -931,6 +1386,15 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
     // phase 2: the grid values at the bound (last point of the shortest function).  One generic-step site.
     int i = p0, pm = e.pm, phase = later ? 1 : 0;
     double lastg = e.lastg;
+    // L == 2, the consumption column in global memory: a batch only copies it to the rows it keeps -- but the wave cannot wait
+    // for that load without waiting for the row stores of the batch before as well (vector memory operations retire in
+    // order, the compiler waits for all of them at the top of the loop), a round trip of about a microsecond per batch of 64
+    // positions and most of the walk's time (profiles/r03_*).  So the batches do not touch the column at all: a consumed
+    // position's class word is replaced by the row it went to (-1: none), and when the walk is over all threads of the
+    // workgroup copy the column to the rows in one parallel pass (run_walk).  A walk that has to be done again (a failed
+    // prediction of the segmented walk) classifies the stream again first.
+    constexpr bool CDEFER = ENV_CDEFER(L);
+    typename EgMem<L>::I *const clsw = const_cast<typename EgMem<L>::I *>(e.cls);
 #ifdef EGDST_STAMPS
     unsigned long long w_t0 = wall_clock64(), w_step = 0, w_batch = 0, w_nstep = 0, w_nbatch = 0;
 #define WSTAMP(acc, cnt) do { unsigned long long n_ = wall_clock64(); acc += n_ - w_t0; w_t0 = n_; cnt++; } while (0)
@@ -942,14 +1406,17 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
         if (phase != 1) {
             if (!(e.m[i] <= e.bound)) break;
         } else {
+            // The regular batches are a loop of their own, entered with no vector memory operation pending (EG_VM_DRAIN):
+            // inside it the wave only issues row stores, which nothing waits for.
+            bool tail = false;
+            EG_VM_DRAIN();
+            for (;;) {
             const int p = i + lane;
             const bool valid = p < p1 && e.m[p] < e.bound;
             const unsigned long long vmask = __ballot(valid);
             if (!(vmask & 1ull)) {  // position i is at (or beyond) the bound: sequential tail with rebuilt cursors
-                for (int j = lane; j < e.nf; j += EG_WAVE) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
-                (void)__ballot(1);  // wave-wide: every cursor is written before lane 0 steps
-                phase = 2;
-                continue;
+                tail = true;
+                break;
             }
             int cls = 1, f = -1;  // 0 keep, 1 skip, 2 event
             double x = 0, fv = 0, cc = 0;
@@ -958,7 +1425,7 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
                 f = e.f[p];
                 x = e.m[p];
                 fv = e.v[p];
-                cc = e.c[p];
+                if (!CDEFER) cc = e.c[p];
                 const int w = e.cls[p];
                 if (w < 0)
                     cls = 2;
@@ -996,41 +1463,44 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
                     const int d = e.oi + __popcll(omask & ((1ull << lane) - 1ull));
                     e.og[d] = x;
                     e.ov[d] = fv;
-                    e.oc[d] = cc;
+                    if (CDEFER)
+                        clsw[p] = d;
+                    else
+                        e.oc[d] = cc;
                 }
                 e.oi += nout;
                 lastg = __shfl(x, 63 - __clzll((long long)omask));  // grid value of the last point kept in this batch
             }
+            if (CDEFER && valid && lane < stop && !out) clsw[p] = -1;  // consumed, no row
             i += stop;
             step_now = stop < nvalid;
-            if (step_now) {  // irregular position: rebuild the per-function cursors for the generic step, a lane each
+            WSTAMP(w_batch, w_nbatch);
+            if (step_now || !(i < p1)) break;
+            }
+            if (tail || step_now) {  // the sequential tail / an irregular position: the generic step needs the per-function cursors, a lane each
                 for (int j = lane; j < e.nf; j += EG_WAVE) e.cur[j] = (e.dims[j] > 0) ? env_count_before(e, j, i) - 1 : -1;
                 (void)__ballot(1);  // wave-wide: every cursor is written before lane 0 steps
             }
-            WSTAMP(w_batch, w_nbatch);
+            if (tail) {
+                phase = 2;
+                continue;
+            }
         }
         if (step_now) {
             e.lastg = lastg;  // rows committed by the batches since the last generic step
             bool ok_;
-#if ENV_SEQ_NF > 0
-            // (experiment, off: walks of few functions take the generic step as the reference's own plain loop on ONE lane --
-            //  env_step / env_crossing -- and hand the scalar state to the others.  Measured on C2 x 4096: 6.55 us per step
-            //  against 6.03 us wave-cooperative, and 23 more spilled VGPRs in a kernel that has none to spare: 175 ms against 170.)
-            if (e.nf <= ENV_SEQ_NF) {
-                EG_WSYNC();  // (the rebuilt cursors are in place)
-                int okl = 1;
-                if (lane == 0) okl = env_step(e, i) ? 1 : 0;
-                EG_WSYNC();
-                ok_ = __shfl(okl, 0) != 0;
-                e.oi = __shfl(e.oi, 0), e.oj = __shfl(e.oj, 0), e.ci = __shfl(e.ci, 0), e.pm = __shfl(e.pm, 0);
-                e.err = __shfl(e.err, 0);
-                e.lastg = __shfl(e.lastg, 0);
-            } else
-#endif
+            if (ENV_LANES(L) && e.nf <= EG_WAVE)
+                ok_ = env_step_lanes<L, OLDSTEP>(e, i);
+            else if (OLDSTEP)
                 ok_ = env_step_wave(e, i);
+            else {  // (the caller promised at most a wave's worth of functions)
+                e.err = 2701;
+                ok_ = false;
+            }
             lastg = e.lastg;
             pm = e.pm;
             if (!ok_) return;
+            if (CDEFER && lane == 0) clsw[i] = -1;  // (whatever row the step kept, it wrote whole)
             i++;
             if (phase == 0 && e.oj > 0) phase = 1;
             WSTAMP(w_step, w_nstep);
@@ -1038,6 +1508,7 @@ template <int L> static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L>
     }
     e.pm = pm;
     e.lastg = lastg;
+    e.iend = i;
 #if defined(EGDST_STAMPS) && !defined(EGDST_STAMPS2) && !defined(EGDST_STAMPS3)
     if (lane == 0 && e.dbg) {
         atomicAdd((unsigned long long *)e.dbg + 3, (w_nbatch << 32) | w_nstep);

@@ -2349,6 +2349,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     // which starts from the true initial state) and is compacted in place; otherwise -- an exact tie at a cut, an error,
     // a full grid -- wave 0 simply does the whole walk again sequentially.  Same code per position either way.
     __shared__ int sg_p[ENV_MAXSEG + 1], sg_oi[ENV_MAXSEG], sg_oj[ENV_MAXSEG], sg_err[ENV_MAXSEG], sg_pm[ENV_MAXSEG], sg_n, sg_next;
+    __shared__ int sg_end[ENV_MAXSEG];  // first position a segment's walk did not consume
     __shared__ double sg_lastg[ENV_MAXSEG];
     const int tid_ = (int)threadIdx.x, wave_ = tid_ / WAVE, lane_ = tid_ & (WAVE - 1);
     int nseg = 1, thstride = j.nthrhmax, thcap = j.nthrhmax;
@@ -2488,6 +2489,7 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             if (lane_ == 0) {
                 sg_oi[sgi] = e.oi, sg_oj[sgi] = e.oj, sg_err[sgi] = e.err, sg_pm[sgi] = e.pm;
                 sg_lastg[sgi] = e.lastg;
+                sg_end[sgi] = e.iend;
                 nx = atomicAdd(&sg_next, 1);
             }
             sgi = __shfl(nx, 0);
@@ -2504,6 +2506,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
                     if (sg_pm[k] != (int)f[q] || !(sg_lastg[k] == m[q])) ok = 0;
                 }
             }
+#ifdef EGDST_EMU
+            if (getenv("EGDST_EMU_FAIL_SEG")) ok = 0;  // harness: every segmented walk is done again by one wave
+#endif
             if (sg_oj[0] <= 0) ok = 0;                             // (segment 0 must have left the first-point phase)
             if (toi >= j.ocap || toj >= j.nthrhmax) ok = 0;      // a full grid or threshold list: the sequential walk reports it
             sg_n = ok ? nseg : 0;
@@ -2530,6 +2535,16 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
                 j.oix[r] = wIX[(size_t)k * thstride + q];
             }
             STAMP2(7);  // check + gather
+            if (ENV_CDEFER(L)) {  // the consumption of the rows the batches kept (env_walk_wave), over the gathered rows
+                __syncthreads();
+                int k = 0, offk = 0;
+                for (int p = tid_; p < j.npts; p += ENV_BS) {
+                    while (p >= sg_p[k + 1]) offk += sg_oi[k], k++;
+                    if (p >= sg_end[k]) continue;
+                    const int d = cls[p];
+                    if (d >= 0) j.oc[offk + d] = c[p];
+                }
+            }
             if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
             return;
         }
@@ -2537,12 +2552,25 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
         e.cur = j.cur, e.mark = j.mark, e.stack = j.stack, e.stackcap = j.stackcap;
         e.og = j.og, e.ov = j.ov, e.oc = j.oc, e.oth = j.oth, e.oix = j.oix;
         e.ocap = j.ocap, e.nthrhmax = j.nthrhmax, e.err = 0;
+        if (ENV_CDEFER(L)) {  // (the segments left row numbers where the class words were)
+            env_preclass(e, j.npts, cls, (int)threadIdx.x, ENV_BS);
+            __syncthreads();
+        }
     }
     if ((int)threadIdx.x < WAVE) {
         env_walk_wave(e, j.npts);
         *err = e.err;
         *n = e.oi;
         *nth = e.oj;
+        if (ENV_CDEFER(L) && lane_ == 0) sg_end[0] = e.err ? 0 : e.iend;
+    }
+    if (ENV_CDEFER(L)) {  // the consumption of the rows the batches kept (env_walk_wave)
+        __syncthreads();
+        const int pe = sg_end[0];
+        for (int p = tid_; p < pe; p += ENV_BS) {
+            const int d = cls[p];
+            if (d >= 0) j.oc[d] = c[p];
+        }
     }
 #ifdef EGDST_STAMPS2
     __syncthreads();
