@@ -800,17 +800,14 @@ template <int L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L>
 #ifndef ENV_LANE_STEP
 #define ENV_LANE_STEP 1
 #endif
-// Which walks take it: those of the throughput path (L == 2) always; k_envelope's LDS-resident streams (L == 1) when the kernel
-// has its full register budget -- the build for big batches (-DENV_MINW=3, 168 VGPRs) spills 569 VGPRs with it against 222
-// without, and its leftover cells took twice as long (bench leg c2_a0_minus5_batch: 448 ms against 357); streams in global
-// memory (L == 0) never: the lanes load the segments of ALL functions at every step, dozens of scattered reads for the long
-// lists of C5 where env_step_wave touches the two or three functions it needs (C5 x 128: k_envelope 1.98 s against 1.76 s).
+// Which walks take it: those of the throughput path (L == 2, k_tp_walk: 168 VGPRs, nothing spilled).  k_envelope does not
+// (-DENV_LANE_STEP_ENV=1 turns it on for its LDS-resident streams, L == 1): the kernel is at its register limit, and the second
+// implementation of the step costs it spills -- 81 VGPRs against 30 in the default build, 569 against 222 in the 168-VGPR
+// build for big batches.  Measured: C2 single solve 8.75 -> 8.45 ms, but C3 single solve 22.1 -> 25.0 ms, the leftover cells of
+// the C2 a0 = -5 batch 357 -> 448 ms per step, and for streams in global memory (L == 0, never) the lanes load the segments of
+// ALL functions at every step where env_step_wave touches the two or three it needs: C5 x 128 k_envelope 1.76 -> 1.98 s.
 #ifndef ENV_LANE_STEP_ENV
-#if defined(ENV_MINW) && ENV_MINW >= 3
 #define ENV_LANE_STEP_ENV 0
-#else
-#define ENV_LANE_STEP_ENV 1
-#endif
 #endif
 #define ENV_LANES(L) (ENV_LANE_STEP && ((L) == 2 || ((L) == 1 && ENV_LANE_STEP_ENV)))
 // Vector memory operations retire in order and share one counter (loads and stores alike, gfx9): where a register that a
