@@ -646,6 +646,27 @@ def test_solver_gateway_third_output_dbgout(name):
     assert np.array_equal(out[:n][out[:n, 2] == -1, 3], th)   # the primary rows are the thresholds of the D cells
 
 
+def test_captured_graph_is_dropped_when_the_kink_log_is_switched(monkeypatch):
+    """EGDST_GRAPH=1: a solve captured while the kink log was on holds the log's device pointers in its nodes; switching the
+    log off frees them, so the captured sequence must go with them (egdst_set_dbgout) -- solve with the log, switch it off, solve
+    again (replaying the old graph would write into freed memory), switch it on again: every solve equals the oracle's and the
+    log of the last one is the oracle's."""
+    monkeypatch.setenv('EGDST_GRAPH', '1')
+    m = examples.retirement2()
+    lib = build.build_model(m)
+    s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
+    s.set_params(m.param_vector()[None])
+    ref = Oracle(m).solve(dbgout=True)
+    for on in (True, False, False, True):
+        s.set_dbgout(on)
+        assert s.solve(raise_on_error=False) == 0
+        ok, rep = compare(s.solution(0), ref, rtol=0.0, th_tol=0.0)
+        assert ok, (on, rep)
+    out, n = s.dbgout(0)
+    assert n == ref.dbgn and np.array_equal(out, ref.dbgout)
+    s.close()
+
+
 def test_class_surface_dbgout():
     m = examples.retirement2()
     m.compile()
