@@ -144,7 +144,7 @@ def pmc_metrics(workload, ndraw, kernel):
         return {}
 
 CLASS_NAMES = ['probe', 'grid', 'k_envelope', 'regeneration', 'tp_prep', 'tp_sort0', 'tp_sort1', 'tp_walk0', 'tp_walk1']
-CLASS_KERNELS = [['k_probe'], ['k_grid_lds', 'k_grid_wide', 'k_grid', 'k_grid_lds_n'], ['k_envelope'], ['k_fixup'], ['k_tp_prep'], ['k_tp_sort'],
+CLASS_KERNELS = [['k_probe'], ['k_grid_lds_cv', 'k_grid_lds', 'k_grid_wide', 'k_grid', 'k_grid_lds_n'], ['k_envelope'], ['k_fixup'], ['k_tp_prep'], ['k_tp_sort'],
                  ['k_tp_sort'], ['k_tp_walk'], ['k_tp_walk']]
 
 

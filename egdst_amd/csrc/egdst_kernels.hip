@@ -950,7 +950,9 @@ template <class P> static __device__ __forceinline__ int eg_bracket_near(double 
 
 // eg_term + eg_next_value for keep == 1 with the M column in LDS and one search (see above).  ibr: nullptr, or in: the
 // bracket of the neighbouring asset point (< 0: none), out: this point's.
-static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_ldsd *M, const Tab &t, const ms_pv *cur, ms_pv *nxt,
+// TT: Tab (C and V in global memory) or TabL (staged in LDS as well, k_grid_lds_cv)
+template <class TT>
+static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_ldsd *M, const TT &t, const ms_pv *cur, ms_pv *nxt,
                                                      double pr1, double *t_rhs, double *t_evf, int *ibr = nullptr)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
@@ -1099,7 +1101,9 @@ __global__ void __launch_bounds__(GRID_BS) k_sortcheck(const Batch *bp_, int it)
 // accumulation per point is the reference's -- and a point starts its bracket search from its predecessor's bracket
 // (eg_bracket_near): the verdict of round 2 on this kernel was "issue-bound on integer work", four of five issue slots
 // address arithmetic and compares of searches that land a row or two from where the neighbouring point's search landed.
-template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(BatchRef b, int it, int lrows)
+// CV: the C and V columns are staged too (whole columns only; the dynamic LDS then holds 3 x lrows doubles): no global read is
+// left in the loop over (next state, shock node) -- k_grid_lds_cv, below
+template <int PPL, bool CV = false> static __device__ __forceinline__ void eg_grid_lds_body(BatchRef b, int it, int lrows)
 {
     EG_DYN_LDS(gl_dyn);                       // [lrows] staged M columns, consecutive by next state
     __shared__ int gl_off[MS_NST], gl_ok;     // first staged row of a next state (-1: not staged), staging succeeded
@@ -1122,6 +1126,7 @@ template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(Batch
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
     const int ny = b.g.ny;
     eg_ldsd *LM = (eg_ldsd *)gl_dyn;
+    eg_ldsd *LC = LM + lrows, *LV = LM + 2 * (size_t)lrows;  // (CV only)
     // ---- stage: which next states, how many rows, are the columns in order -------------------------------------
     if (threadIdx.x == 0) {
         int tot = 0, ok = (ny <= EG_GRID_NYMAX || !MS_SHOCK_NODES_SHARED) ? 1 : 0;
@@ -1140,6 +1145,7 @@ template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(Batch
             tot += len;
         }
         int stride = 1;
+        if (CV && ok && tot > lrows) ok = 0;  // (whole columns or the general path)
         if (ok && tot > lrows) {
             // too long: a sampled index of every column; needs the tables in order (k_sortcheck ran before this kernel)
             int nfe = 0;
@@ -1195,6 +1201,7 @@ template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(Batch
             for (int r = threadIdx.x; r < t.len; r += GRID_BS) {
                 const double m = t.M[r];
                 LM[off + r] = m;
+                if (CV) LC[off + r] = t.C[r], LV[off + r] = t.V[r];
                 if (r + 1 < t.len && !(m <= t.M[r + 1])) bad = 1;  // (NaN counts as out of order)
             }
             if (MS_SHOCK_NODES_SHARED) {
@@ -1285,6 +1292,12 @@ template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(Batch
                     checksum[j] += pr1;
                     cnt[j]++;
                     double t_rhs, t_evf;
+                    if (CV) {
+                        TabL tl;
+                        tl.M = M, tl.C = (const eg_ldsd *)LC + gl_off[nxt.ist], tl.V = (const eg_ldsd *)LV + gl_off[nxt.ist];
+                        tl.TH = t.TH, tl.D = t.D, tl.len = t.len, tl.thlen = t.thlen;
+                        c1[j] = eg_term_lds(&E, M, tl, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr);
+                    } else
                     c1[j] = (stride > 1) ? eg_term_sampled(&E, M, ns, stride, edge, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr)
                                          : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr);
                     if (c1[j] > 0) {
@@ -1350,6 +1363,12 @@ template <int PPL> static __device__ __forceinline__ void eg_grid_lds_body(Batch
 __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds(const Batch *bp_, int it, int lrows)
 {
     eg_grid_lds_body<1>(EG_BATCH_REF(bp_), it, lrows);
+}
+// Whole tables in LDS -- M, C and V, 24 B per row -- for batches whose tables fit: the loop over (next state, shock node) then
+// reads nothing from global memory (four scattered 8-byte reads per term in k_grid_lds, the C and V of the bracket's two rows).
+__global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds_cv(const Batch *bp_, int it, int lrows)
+{
+    eg_grid_lds_body<1, true>(EG_BATCH_REF(bp_), it, lrows);
 }
 #ifndef GRID_N_MINW
 #define GRID_N_MINW 1  // (the lane's points side by side want registers: 133 VGPRs by default, three waves per SIMD)

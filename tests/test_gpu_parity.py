@@ -535,7 +535,7 @@ def test_device_math_equals_host_libm():
 
 
 @pytest.mark.parametrize('name', ['retirement2', 'occ3', 'retire8', 'deaton2', 'model2', 'C2', 'C2_a0neg_T60', 'occ3_n400'])
-@pytest.mark.parametrize('lds', ['lds', 'sampled', 'general'])
+@pytest.mark.parametrize('lds', ['lds', 'lds_cv', 'sampled', 'general'])
 def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
     """A single draw normally takes k_grid_wide (16 lanes per point).  Forced through the kernels big batches use --
     k_grid_lds (searched columns in LDS, one bracket search per evaluation, shared shock nodes) and the general k_grid --
@@ -543,7 +543,9 @@ def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
     monkeypatch.setenv('EGDST_GRID_WIDE', '0')
     # 2048 rows of LDS hold whole columns; 64 force the sampled index (every k-th row in LDS, the search finished in the
     # global column: the form C4 and C5 take); 0 is the general kernel with two searches in global memory
-    monkeypatch.setenv('EGDST_GRID_LDS', {'general': '0', 'sampled': '64', 'lds': '2048'}[lds])
+    # lds_cv: the C and V columns in LDS as well (k_grid_lds_cv: no global read in the loop over the shock nodes)
+    monkeypatch.setenv('EGDST_GRID_LDS', {'general': '0', 'sampled': '64', 'lds': '2048', 'lds_cv': '2048'}[lds])
+    monkeypatch.setenv('EGDST_GRID_CV', '1' if lds == 'lds_cv' else '0')
     m = (CASES.get(name) or SCALED[name])()
     s = gpu_solve(m)
     sol, ref = s.solution(0), Oracle(m).solve()

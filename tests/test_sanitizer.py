@@ -239,3 +239,15 @@ def test_estimation_step_kernels():
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'estimation problems: 0' in r.stdout, r.stdout + r.stderr[-2000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(_asan() is None, reason='libasan not found')
+def test_grid_kernel_with_whole_tables_in_lds():
+    """EGDST_GRID_CV=1: k_grid_lds_cv -- M, C and V of the next-period table staged in LDS, no global read in the loop over the shock
+    nodes -- bit-exact against the oracle, ASan clean."""
+    e = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_GRID_CV='1', EGDST_GRID_WIDE='0')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py'), 'retirement2', 'T=8, ngridm=60'], env=e,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
