@@ -74,6 +74,7 @@ struct Batch {
     struct TpCell *tpcell;              // [ndraw*MS_NST]
     unsigned *tpstat;                   // [2*ndraw] cells of the draw the throughput path completed / left to k_envelope, this solve
     int *tpn, *tplist;                  // [MAX_GROUPS * nt] cells per (group, period) left to k_envelope; [ndraw*MS_NST] their slots, a group's at its first
+    int *tpbign, *tpbiglist;            // the same for the cells of the second tier of stage 1 (lists beyond the regular stream budget, k_tp_*_big)
     // status
     int *status;          // [ndraw] first error code
     int *where;           // [2*ndraw] (it, ist) of that error
@@ -244,12 +245,20 @@ static __device__ __forceinline__ Tab eg_tab(BatchRef b, int slot, int draw, int
 // Next-period value at nxt->cash (valuefunc, egdst_solver.c:755-772 with linter_extrap, egdst_lib.c:179-206).
 // ibr: -1, or the bracket linter's search found for the same x over (M, len) when the column is known to be non-decreasing
 // and len >= 4: valuefunc's search over the column shifted by one row then follows from it (k_grid_lds, eg_second_bracket).
-template <class TT> static __device__ __forceinline__ double eg_next_value(const ms_env *E, const TT &t, const ms_pv *nxt, int ibr = -1)
+// verr: set when the table has fewer than two rows beside the a0 row and the analytic branch does not apply: linter_extrap then
+// reports "At least two points are required for interpolation!" (egdst_lib.c:183) and the solver returns at once
+// (egdst_solver.c:567-568).  A table of one row is what the envelope of a guess stream that ended in the generator's resend fixed
+// point leaves behind (C2 with a0 = -5: ~6 % of the parameter draws).
+template <class TT> static __device__ __forceinline__ double eg_next_value(const ms_env *E, const TT &t, const ms_pv *nxt, int ibr = -1, int *verr = nullptr)
 {
     const double evf1 = t.V[0], a0 = E->a0, x = nxt->cash;
     if (x < t.M[1] && evf1 > -INFINITY) return ms_utility(E, nxt, x - a0) + ms_discount(E, nxt) * evf1;
     const auto g = t.M + 1, f = t.V + 1;
     const int n = t.len - 1;
+    if (n < 2) {
+        if (verr) *verr = 1;
+        return -1.0;
+    }
     int i = (ibr >= 0) ? ((x < t.M[2]) ? 0 : ((x >= t.M[t.len - 2]) ? t.len - 3 : ibr - 1)) : eg_bracket(x, g, n, 0);
     double f0 = f[i], f1 = f[i + 1];
     if (!isfinite(f0)) return f0;
@@ -267,7 +276,7 @@ template <class TT> static __device__ __forceinline__ double eg_next_value(const
 // sorted: the table's M column is known to be non-decreasing (k_sortcheck) -- one bracket search serves both interpolations.
 template <class TT>
 static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, const ms_pv *cur, ms_pv *nxt,
-                                                 double pr1, int keep, double *t_rhs, double *t_evf, int sorted = 0)
+                                                 double pr1, int keep, double *t_rhs, double *t_evf, int sorted = 0, int *verr = nullptr)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const int n1 = t.len;
@@ -282,7 +291,7 @@ static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, c
     else
         nxt->id = 0;
     *t_rhs = pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
-    if (keep == 1) *t_evf = pr1 * eg_next_value(E, t, nxt, (sorted && n1 >= 4) ? i : -1);
+    if (keep == 1) *t_evf = pr1 * eg_next_value(E, t, nxt, (sorted && n1 >= 4) ? i : -1, verr);
     return c1;
 }
 

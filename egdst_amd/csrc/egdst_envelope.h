@@ -820,6 +820,9 @@ template <int L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L>
 #else
 #define EG_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0), nothing else
 #endif
+#ifndef ENV_DUPRUN
+#define ENV_DUPRUN 1  // runs of repeated grid values at the bound are consumed 64 positions at a time (env_walk_wave); 0: one generic step each (tests)
+#endif
 #ifndef ENV_CDEFER_ON
 #define ENV_CDEFER_ON 1  // walks with the consumption column in global memory copy it to the kept rows after the walk (env_walk_wave)
 #endif
@@ -1402,6 +1405,41 @@ static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, in
         bool step_now = true;
         if (phase != 1) {
             if (!(e.m[i] <= e.bound)) break;
+            // A run of positions that repeat the grid value of the last output row (:1290-1298).  The generic step does
+            // nothing for such a position but advance its function's cursor by one -- no row, no threshold, the grid value
+            // stays -- so the next position with the same value is in the same case, and so on to the end of the run: the run
+            // is consumed here, 64 positions at a time, with the same cursor increments.  (A guess stream that ended in the
+            // generator's resend fixed point -- k_probe / k_fixup fast-forward it -- brings ~9000 copies of its last point, and
+            // that point is the bound of the secondary envelope: one generic step per copy was 6 ms for such a cell.)
+            if (ENV_DUPRUN && phase == 2 && (e.oi > 0 || e.later) && lastg == e.m[i]) {
+                const double x0 = lastg;
+                for (;;) {
+                    const int p = i + lane;
+                    int fp = -1;
+                    bool rep = false;
+                    if (p < p1) {
+                        fp = e.f[p];
+                        rep = e.m[p] == x0 && fp >= 0 && fp < e.nf;
+                        if (rep) rep = e.dims[fp] > 0;  // (an inconsistent stream is the generic step's to report)
+                    }
+                    const unsigned long long notrep = ~__ballot(rep) & (EG_WAVE >= 64 ? ~0ull : ((1ull << (EG_WAVE & 63)) - 1ull));
+                    const int run = notrep ? (__ffsll((long long)notrep) - 1) : EG_WAVE;  // leading positions of the chunk in the run
+                    const bool mine = lane < run;
+                    unsigned long long todo = __ballot(mine);
+                    EG_WSYNC();
+                    while (todo) {  // one turn per function with points in the chunk (normally one)
+                        const int g = __shfl(fp, __ffsll((long long)todo) - 1);
+                        const unsigned long long same = __ballot(mine && fp == g);
+                        if (lane == 0) e.cur[g] = e.cur[g] + __popcll(same);
+                        todo &= ~same;
+                    }
+                    EG_WSYNC();
+                    if (CDEFER && mine) clsw[p] = -1;  // consumed, no row
+                    i += run;
+                    if (run < EG_WAVE || !(i < p1)) break;
+                }
+                continue;  // (the loop's own tests decide about position i: the end of the range, the bound)
+            }
         } else {
             // The regular batches are a loop of their own, entered with no vector memory operation pending (EG_VM_DRAIN):
             // inside it the wave only issues row stores, which nothing waits for.

@@ -93,6 +93,30 @@ static __device__ __forceinline__ size_t eg_cand(BatchRef b, int draw, int ist, 
     return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.Cp;
 }
 
+#ifdef EGDST_CENSUS
+// Diagnostic build (tests/diag/gpu_census.py): a log of what the slow paths of a batch were given to do -- 8 ints per record:
+// kind, draw, it, a, b, c, d, ticks of 10 ns.  kinds: 1 a sort + walk job of k_envelope (a job, b points, c functions | path << 16,
+// d why the throughput path left the cell), 2 a cell of k_envelope (a rows out, b thresholds, c error, d why), 3 a stream of
+// k_fixup (a choice, b points kept, c calls), 4 a k_probe wave that took long (a choice, b calls, c fast-forwarded calls),
+// 5 a walk of the throughput path that gave up (a stage, b error, c points, d rows).
+#define EG_CENSUS_CAP (1 << 20)
+__shared__ int cz_sh_bad;  // the sort of the current job found a list out of comp1 order (1: network, 2: counted)
+__device__ int g_census[EG_CENSUS_CAP * 8];
+__device__ unsigned g_census_n;
+static __device__ __forceinline__ void eg_census(int kind, int draw, int it, int a, int b_, int c, int d, unsigned long long ticks)
+{
+    const unsigned k = atomicAdd(&g_census_n, 1u);
+    if (k >= EG_CENSUS_CAP) return;
+    int *o = g_census + 8 * (size_t)k;
+    o[0] = kind, o[1] = draw, o[2] = it, o[3] = a, o[4] = b_, o[5] = c, o[6] = d, o[7] = (int)(ticks > 0x7fffffffull ? 0x7fffffffull : ticks);
+}
+#define EG_CENSUS(...) eg_census(__VA_ARGS__)
+#define EG_CENSUS_BAD(v) do { if (threadIdx.x == 0) cz_sh_bad = (v); } while (0)
+#else
+#define EG_CENSUS_BAD(v) ((void)0)
+#define EG_CENSUS(...) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // terminal period (egdst_solver.c:433-476, END2): M_i = trinv(m1 + i (m2-m1)/(ngridm-1)), C = M, V = u(C)
 __global__ void __launch_bounds__(GRID_BS) k_terminal(const Batch *bp_, int it)
@@ -229,12 +253,18 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env
             checksum += pr1;
             cnt++;
             double t_rhs, t_evf;
-            c1 = eg_term(E, t, cur, &nxt, pr1, 1, &t_rhs, &t_evf, tsorted);
+            int verr = 0;
+            c1 = eg_term(E, t, cur, &nxt, pr1, 1, &t_rhs, &t_evf, tsorted, &verr);
             if (c1 <= 0) break;
             rhs += t_rhs;
+            if (verr) {  // valuefunc on a table with one row beside the a0 row (egdst_lib.c:183, egdst_solver.c:567-568)
+                status = -10;
+                break;
+            }
             evf += t_evf;
             if (evf == -INFINITY) break;
         }
+        if (status) break;
         if (c1 <= 0 || evf == -INFINITY) {
             r.bist = nxt.ist;
             r.bshock = nxt.shock;
@@ -316,6 +346,7 @@ static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_e
         for (int base = 0; base < niy && status == 0; base += GW) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
+            int verr = 0;  // this lane's term: valuefunc on a table with one row beside the a0 row (eg_next_value)
             if (iy < niy) {
                 ms_pv nl = nxt;
                 if (niy == 1) {
@@ -326,7 +357,7 @@ static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_e
                     pr1 = MS_OPTIM_TRPRNOSH ? pr1pre : ms_trpr(E, cur, &nl, &terr);
                     pr1 *= b.qw[iy];
                 }
-                if (pr1 != 0.0) c1 = eg_term(E, t, cur, &nl, pr1, keep, &t_rhs, &t_evf, tsorted);
+                if (pr1 != 0.0) c1 = eg_term(E, t, cur, &nl, pr1, keep, &t_rhs, &t_evf, tsorted, &verr);
                 shock = nl.shock;
                 cash = nl.cash;
             }
@@ -347,6 +378,10 @@ static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_e
                 }
                 rhs += __shfl(t_rhs, gbase + l);
                 if (keep == 1) {
+                    if (__shfl(verr, gbase + l)) {  // (egdst_lib.c:183, egdst_solver.c:567-568: the solver returns at once)
+                        status = -10;
+                        break;
+                    }
                     evf += __shfl(t_evf, gbase + l);
                     if (evf == -INFINITY) {
                         status = 2;
@@ -441,6 +476,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
 #ifdef EGDST_FIXSTAT  // diagnostic: what a regeneration consists of (dbg ints 8..11, ticks in ints 12-13)
     int fs_batches = 0, fs_single = 0, fs_resend = 0;
     const unsigned long long fs_t0 = wall_clock64();
+#endif
+#ifdef EGDST_CENSUS
+    const unsigned long long cz_t0_ = wall_clock64();
 #endif
     for (;;) {
         // ---- next guess -------------------------------------------------------------------
@@ -776,6 +814,13 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
         atomicAdd(&b.dbg[16 * draw + 8], fs_batches), atomicAdd(&b.dbg[16 * draw + 9], fs_single);
         atomicAdd(&b.dbg[16 * draw + 10], fs_resend), atomicAdd(&b.dbg[16 * draw + 11], 1);
         atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 6, wall_clock64() - fs_t0);
+    }
+#endif
+#ifdef EGDST_CENSUS
+    if (lead) {
+        const unsigned long long cz_ = wall_clock64() - cz_t0_;
+        if (full) EG_CENSUS(3, draw, it, id, np, ncalls, skipped, cz_);
+        else if (cz_ > 5000ull) EG_CENSUS(4, draw, it, id, ncalls, skipped, np, cz_);
     }
 #endif
     // re-basing calls of this stream beyond the regular ones: the host schedules draws with many of them apart
@@ -1784,6 +1829,7 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     for (int i = threadIdx.x + 1; i < npts; i += ENV_BS)
         if (ifn[i] == ifn[i - 1] && !pt_before(im[i - 1], iv[i - 1], ifn[i - 1], i - 1, im[i], iv[i], ifn[i], i)) bad = 1;
     bad = blk_sum(bad, sh);
+    EG_CENSUS_BAD(bad ? 1 : 0);
     TPST(0);
     TPCNT(4, 1);
     TPCNT(5, bad ? 1 : 0);
@@ -2071,6 +2117,7 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
     int P = 1;
     while (P < npts) P <<= 1;
     if (bad && P > lcap) bad = 2;  // no room for the padded network: counting ranks instead
+    EG_CENSUS_BAD(bad);
     ST3(3);
     if (bad != 1) {
         double kbound = INFINITY;  // min over the functions of their last grid value (:1266-1271)
@@ -2218,9 +2265,15 @@ static __device__ __forceinline__ eg_ldss *blk_sort_lds(int npts, int nf, const 
 
 // ---------------------------------------------------------------------------------------------
 // Stop rule, compaction, secondary and primary envelopes, output rows for one (draw, ist).
+#ifdef EGDST_CENSUS
+#define ENV_FAIL_CENSUS(code) EG_CENSUS(2, draw, it, -1, -1, (code), cz_why_, wall_clock64() - cz_cell0_)
+#else
+#define ENV_FAIL_CENSUS(code) ((void)0)
+#endif
 #define ENV_FAIL(code)                                                                    \
     do {                                                                                  \
         if (tid == 0) {                                                                   \
+            ENV_FAIL_CENSUS(code);                                                        \
             if (part == 1) /* part 2 reports the first error of the cell in choice order */ \
                 b.secerr[cell * MS_ND + pid] = (code);                                    \
             else {                                                                        \
@@ -2646,6 +2699,10 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
         b.secev[cell * MS_ND + pid] = 0.0;
         b.secevals[cell * MS_ND + pid] = 0ull;
     }
+#ifdef EGDST_CENSUS
+    const unsigned long long cz_cell0_ = wall_clock64();
+    const int cz_why_ = (pass == 1) ? b.defer[cell] : 0;
+#endif
     if (pass == 1) {
         if (!b.defer[cell]) return;  // done in pass 0
         __syncthreads();
@@ -3017,11 +3074,18 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
             cv.cash = cv.savings = cv.shock = 0;
             return ms_utility(&E, &cv, x - E.a0) + ms_discount(&E, &cv) * ev;
         };
+#ifdef EGDST_CENSUS
+        const unsigned long long cz_job0_ = wall_clock64();
+        unsigned long long cz_sort1_ = cz_job0_;
+#endif
         int fused = 0;
         if (job.npts <= lcap) {
             const eg_ldss *posl = blk_sort_lds(job.npts, job.nf, iM, iC, iV, iF, fstart, fdims, R1, R2, R3, Lf, Lr, lcap,
                                                sh, &s_oob, Lq, &fused, ana, job.dbg);
             STAMP(3);  // LDS sort
+#ifdef EGDST_CENSUS
+            cz_sort1_ = wall_clock64();
+#endif
             if (s_oob) ENV_FAIL(2704);
             {
                 int we = 0, wn = 0, wm = 0;
@@ -3047,6 +3111,9 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
 #else
                           4 * lcap);  // (all of the dynamic LDS, as doubles)
 #endif
+#ifdef EGDST_CENSUS
+            cz_sort1_ = wall_clock64();
+#endif
             if (s_oob) ENV_FAIL(2714);
             {
                 int we = 0, wn = 0, wm = 0;
@@ -3058,6 +3125,11 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
         }
         __syncthreads();
         STAMP(4);  // walk
+#ifdef EGDST_CENSUS
+        // (d: why << 24 | bad << 20 | sort time in us)
+        if (tid == 0) EG_CENSUS(1, draw, it, jb, job.npts, job.nf | ((job.npts <= lcap ? 0 : 1) << 16),
+                                (cz_why_ << 24) | (cz_sh_bad << 20) | (int)min((unsigned long long)0xfffff, (cz_sort1_ - cz_job0_) / 100), wall_clock64() - cz_job0_);
+#endif
         if (s_err) ENV_FAIL(s_err);
         if (!primary) {
             if (s_n >= ngridmax) ENV_FAIL(17);  // (:884)
@@ -3108,6 +3180,9 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
                     oM[1], oC[1], oV[1], oM[outn], oV[outn]);
 #endif
         if (evals) atomicAdd(&b.evals[draw], evals);
+#ifdef EGDST_CENSUS
+        EG_CENSUS(2, draw, it, outn, outm, 0, cz_why_, wall_clock64() - cz_cell0_);
+#endif
 #ifdef EGDST_STAMPS5
         atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 0, wall_clock64() - wg_t0_);
 #endif
@@ -3167,9 +3242,10 @@ __global__ void __launch_bounds__(ENV_MAXBS, ENV_MINW) ENV_VGPR_ATTR k_envelope(
 #define TP_BS 256
 #endif
 static_assert(MS_ND <= TP_NF, "TP_NF must hold one function per choice");
-#define TP_DEFER()                            \
+// (the value written is the reason -- any non-zero value defers the cell; -DEGDST_CENSUS logs it)
+#define TP_DEFER(why)                         \
     do {                                      \
-        if (threadIdx.x == 0) b.defer[cell] = 1; \
+        if (threadIdx.x == 0) b.defer[cell] = (why); \
         return;                               \
     } while (0)
 
@@ -3220,11 +3296,11 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
     const size_t cell = (size_t)draw * MS_NST + ist;
     TpRec *R = b.tprec + cell * MS_ND + id;
     if (tid == 0) R->active = 0, R->cnt = 0, R->nfold = 0, R->fused = 0, R->evfa0 = 0.0, R->evals = 0ull, s_oob = 0;
-    if (b.status[draw]) TP_DEFER();  // (k_envelope clears the lengths of a failed draw's cells)
+    if (b.status[draw]) TP_DEFER(1);  // (k_envelope clears the lengths of a failed draw's cells)
     ms_env E = eg_env(b, draw);
     ms_pv cur;
     cur.it = it, cur.ist = ist, cur.id = 0, cur.cash = cur.savings = cur.shock = 0;
-    if (ms_feasible(&E, &cur) != 1) TP_DEFER();
+    if (ms_feasible(&E, &cur) != 1) TP_DEFER(2);
     const ProbeOut P = b.probe[cell * MS_ND + id];
     if (!P.active) return;
     __syncthreads();
@@ -3298,11 +3374,11 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
     if (fusedstats) {
         blk_reduce3(&hard, &n12, &ev, sh);
         evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
-        if (hard || (n12 & 1)) TP_DEFER();  // a hard error, a zero-consumption signal left over: k_envelope reports them
+        if (hard || (n12 & 1)) TP_DEFER(3);  // a hard error, a zero-consumption signal left over: k_envelope reports them
         if (n12 & 2) evfa0 = -INFINITY;
     }
     __syncthreads();
-    if (s_oob) TP_DEFER();
+    if (s_oob) TP_DEFER(4);
     // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -------------------------------------------
     int nfold = 0;
     if (cnt > 1) {
@@ -3311,7 +3387,7 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
         nfold = blk_sum(nfold, sh);
     }
     if (nfold > 0) {
-        if (id + nfold + 1 > TP_NF) TP_DEFER();
+        if (id + nfold + 1 > TP_NF) TP_DEFER(5);
         // the pieces, one constant-extrapolation point appended to every closed one (:822-835)
         int carry = 0, lastfold = 0;
         for (int base = 0; base < cnt; base += TP_BS) {
@@ -3338,7 +3414,7 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
             carry += tot;
         }
         lastfold = blk_sum(lastfold, sh);
-        if (s_oob || lastfold + (nfold - 1) >= ngridmax) TP_DEFER();  // (:823 not enough space: k_envelope reports it)
+        if (s_oob || lastfold + (nfold - 1) >= ngridmax) TP_DEFER(6);  // (:823 not enough space: k_envelope reports it)
         __syncthreads();
         for (int f = tid; f < id + nfold + 1; f += TP_BS) R->fstart[f] = (f < id) ? 0 : s_fstart[f];
     }
@@ -3355,7 +3431,14 @@ __global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp
 // bxi: stage 0: cell slot * MS_ND + choice; stage 1: cell slot
 // wcap: points the walk of this stage keeps in LDS -- a longer stream (a degenerate guess stream: thousands of repeated
 // points) is k_envelope's, and is not sorted here either; 0: no limit (the walks run on global memory, k_tp_walk_g)
-static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int wcap, int bxi, TpShared *S, double *dynlds)
+// big (stage 1 only): the second tier of the stage -- the cells whose lists exceed the stream budget of the regular launch (wcap:
+// what lets three walks share a CU) but fit the largest one (bigcap) are flagged TP_BIG and listed (biglist, bigcnt) by the
+// regular launch and done by a second, small launch with the large budget (big != 0: bxi comes from that list).  On C2 with the
+// surveyed credit limit a0 = -5 one cell in sixteen has such lists -- the secondary envelope of a regenerated guess stream adds a
+// few hundred rows -- and left to k_envelope they were 55 % of its time (profiles/r04_*).
+#define TP_BIG (-2)
+static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, int lkcap, int wcap, int bxi, TpShared *S, double *dynlds,
+                                               int big = 0, int bigcap = 0, int *biglist = nullptr, int *bigcnt = nullptr)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims;
     double *const s_evfa0 = S->evfa0;
@@ -3364,7 +3447,14 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x, TPB = (int)blockDim.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
-    if (TP_DEFERRED_UNIFORM(S, cell)) return;  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
+    {
+        const int df = TP_DEFERRED_UNIFORM(S, cell);  // (set by k_tp_prep or an earlier stage of this period; a racing setter is caught by the next stage)
+        if (big ? df != TP_BIG : df != 0) return;
+        if (big) {
+            __syncthreads();  // (every thread has the flag: it is this launch's to clear)
+            if (threadIdx.x == 0) b.defer[cell] = 0;
+        }
+    }
 #ifdef EGDST_TPSTAMPS
     const unsigned long long tpk_t0_ = wall_clock64();
 #endif
@@ -3383,7 +3473,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
     if (stage == 0) {
         if (!R->active || R->nfold <= 0) return;
         npts = R->cnt + R->nfold;
-        if (wcap > 0 && npts > wcap) TP_DEFER();
+        if (wcap > 0 && npts > wcap) TP_DEFER(7);
         nf = id + R->nfold + 1;
         for (int f = tid; f < nf; f += TPB) {
             const int a = R->fstart[f], z = (f + 1 < nf) ? R->fstart[f + 1] : npts;
@@ -3399,7 +3489,16 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
         int *pF = b.pF + wo;
         int any = 0, nall = 0;
         for (int k = 0; k < MS_ND; k++) nall += (R + k)->cnt;
-        if (wcap > 0 && nall > wcap) TP_DEFER();
+        if (wcap > 0 && nall > wcap) {
+            if (!big && biglist && nall <= bigcap) {  // the second tier's (nothing of the cell has been touched yet)
+                if (threadIdx.x == 0) {
+                    b.defer[cell] = TP_BIG;
+                    biglist[atomicAdd((unsigned *)bigcnt, 1u)] = bx_;
+                }
+                return;
+            }
+            TP_DEFER(8);
+        }
         nall = 0;
         for (int k = 0; k < MS_ND; k++) {
             const TpRec *Rk = R + k;
@@ -3420,7 +3519,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
             for (int r = tid; r < cntk; r += TPB) pF[nall + r] = k;
             nall += cntk;
         }
-        if (!any || nall == 0) TP_DEFER();  // (errors 14 and 15 of k_envelope)
+        if (!any || nall == 0) TP_DEFER(9);  // (errors 14 and 15 of k_envelope)
         npts = nall, nf = MS_ND;
         iM = pM, iC = pC, iV = pV, iF = pF;
     }
@@ -3462,7 +3561,7 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
 #ifdef EGDST_TPSTAMPS
     if (tid == 0) atomicAdd((unsigned long long *)(b.dbg + 16 * draw) + 7, wall_clock64() - tpk_t0_);
 #endif
-    if (s_oob) TP_DEFER();
+    if (s_oob) TP_DEFER(10);
     if (tid == 0) {
         if (stage == 0)
             R->fused = fused;
@@ -3470,11 +3569,23 @@ static __device__ __forceinline__ void tp_sort(BatchRef b, int it, int stage, in
             b.tpcell[cell].npts = npts, b.tpcell[cell].fused = fused;
     }
 }
-__global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap, int wcap)
+__global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batch *bp_, int it, int stage, int lkcap, int wcap, int bigcap,
+                                                                      int *biglist, int *bigcnt)
 {
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;
-    tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, wcap, (int)blockIdx.x, &S, (double *)dynlds);
+    tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, wcap, (int)blockIdx.x, &S, (double *)dynlds, 0, bigcap, biglist, bigcnt);
+}
+// the second tier of stage 1: a small grid loops over the listed cells
+__global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort_big(const Batch *bp_, int it, int lkcap, const int *biglist, const int *bigcnt)
+{
+    EG_DYN_LDS(dynlds);
+    __shared__ TpShared S;
+    const int n = *bigcnt;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        tp_sort(EG_BATCH_REF(bp_), it, 1, lkcap, lkcap, biglist[k], &S, (double *)dynlds, 1);
+        __syncthreads();  // (the LDS of the cell is reused by the next one)
+    }
 }
 
 // One wave per job.  stage 0: secondary envelope of a folded choice list, result written over the list it came from (dead by
@@ -3484,10 +3595,10 @@ __global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batc
 #endif
 // stage 1 also lists the cells that are left to k_envelope (`list`, `cnt`: this (group, period)'s; every cell's stage-1
 // workgroup runs exactly once, so a cell is listed exactly once whichever kernel flagged it).
-#define TP_DEFER_LISTED()                                                   \
+#define TP_DEFER_LISTED(why)                                                \
     do {                                                                    \
         if (threadIdx.x == 0) {                                             \
-            b.defer[cell] = 1;                                              \
+            b.defer[cell] = (why);                                           \
             list[atomicAdd((unsigned *)cnt, 1u)] = bx_;                     \
             atomicAdd(&b.tpstat[2 * draw + 1], 1u);                         \
         }                                                                   \
@@ -3499,7 +3610,8 @@ __global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batc
 // streams, but as a kernel of its own -- a few KB of LDS and 168 VGPRs, so that several cells share a CU where k_envelope, sized
 // for its LDS-resident streams, takes a CU per cell.
 template <bool GLOBAL>
-static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, int *list, int *cnt, int lcap, int bxi, TpShared *S, double *dynlds)
+static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, int *list, int *cnt, int lcap, int bxi, TpShared *S, double *dynlds,
+                                               int big = 0)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart, *const s_fdims = S->fdims, *const s_fcur = S->fcur, *const s_fmark = S->fmark;
     int *const s_stack = S->stack;
@@ -3509,9 +3621,13 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     const int ist = bx_ % MS_NST, draw = b.order[b.draw0 + bx_ / MS_NST];
     const int tid = threadIdx.x;
     const size_t cell = (size_t)draw * MS_NST + ist;
-    if (TP_DEFERRED_UNIFORM(S, cell)) {
-        if (stage == 1 && tid == 0) list[atomicAdd((unsigned *)cnt, 1u)] = bx_, atomicAdd(&b.tpstat[2 * draw + 1], 1u);
-        return;
+    {
+        const int df = TP_DEFERRED_UNIFORM(S, cell);
+        if (df == TP_BIG && !big) return;  // the second tier of the stage decides about this cell (and lists it if it gives up)
+        if (df) {
+            if (stage == 1 && tid == 0) list[atomicAdd((unsigned *)cnt, 1u)] = bx_, atomicAdd(&b.tpstat[2 * draw + 1], 1u);
+            return;
+        }
     }
     TpRec *R = b.tprec + cell * MS_ND + id;
     if (stage == 0 && (!R->active || R->nfold <= 0)) return;
@@ -3574,7 +3690,7 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
             evals += Rk->evals;
         }
         job.npts = b.tpcell[cell].npts;
-        if (job.npts != nall) TP_DEFER_LISTED();  // (never expected: the sort packed exactly these lists)
+        if (job.npts != nall) TP_DEFER_LISTED(11);  // (never expected: the sort packed exactly these lists)
         job.nf = MS_ND;
         job.sec_id = -1, job.sec_ev = 0;
         job.cap = (int)Wcell;
@@ -3597,8 +3713,8 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
         run_walk<0, true>(&E, job, b.qM + wo, b.qC + wo, b.qV + wo, b.qF + wo, b.rank + wo, b.gcls + wo, &we, &wn, &wm, classified);
     } else {
     if (job.npts > lcap || job.npts >= 65536) {
-        if (stage == 1) TP_DEFER_LISTED();
-        TP_DEFER();
+        if (stage == 1) TP_DEFER_LISTED(12);
+        TP_DEFER(12);
     }
 #ifdef EGDST_EMU
     eg_ldsd *Lm = (eg_ldsd *)dynlds, *Lv = Lm + lcap + 8;
@@ -3644,12 +3760,18 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     __syncthreads();
     we = S->res[0], wn = S->res[1], wm = S->res[2];
     if (stage == 0) {
-        if (we || wn >= b.g.ngridmax) TP_DEFER();  // (:884)
+#ifdef EGDST_CENSUS
+        if ((we || wn >= b.g.ngridmax) && tid == 0) EG_CENSUS(5, draw, it, 0, we, job.npts, wn, 0);
+#endif
+        if (we || wn >= b.g.ngridmax) TP_DEFER(13);  // (:884)
         if (tid == 0) R->cnt = wn;
         TWST(2);
         return;
     }
-    if (we || wn == 0) TP_DEFER_LISTED();  // (wn == 0: error 16 of k_envelope)
+#ifdef EGDST_CENSUS
+    if ((we || wn == 0) && tid == 0) EG_CENSUS(5, draw, it, 1, we, job.npts, wn, 0);
+#endif
+    if (we || wn == 0) TP_DEFER_LISTED(14);  // (wn == 0: error 16 of k_envelope)
     const int outn = wn, outm = wm;
     for (int i = outn + 1 + tid; i < hw_rows; i += TPW) oM[i] = oC[i] = oV[i] = 0.0;
     for (int i = outm + tid; i < hw_th; i += TPW) oTH[i] = oD[i] = 0.0;
@@ -3677,6 +3799,17 @@ __global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk(const Batc
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;
     tp_walk<false>(EG_BATCH_REF(bp_), it, stage, list, cnt, lcap, (int)blockIdx.x, &S, (double *)dynlds);
+}
+__global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk_big(const Batch *bp_, int it, int *list, int *cnt, int lcap, const int *biglist,
+                                                                          const int *bigcnt)
+{
+    EG_DYN_LDS(dynlds);
+    __shared__ TpShared S;
+    const int n = *bigcnt;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        tp_walk<false>(EG_BATCH_REF(bp_), it, 1, list, cnt, lcap, biglist[k], &S, (double *)dynlds, 1);
+        __syncthreads();  // (the LDS of the cell is reused by the next one)
+    }
 }
 #ifdef EGDST_EMU
 #define TP_WALKG_BS ENV_BS_EMU

@@ -217,6 +217,10 @@ static double next_value(ctx_t *c, const ms_pv *nxt)
     double evf1 = gv[0];
     if (nxt->cash < gm[1] && evf1 > -INFINITY)
         return ms_utility(&c->E, nxt, nxt->cash - c->E.a0) + ms_discount(&c->E, nxt) * evf1;
+    if (n1 < 2) { /* linter_extrap, egdst_lib.c:183; the caller returns on it (egdst_solver.c:567-568) */
+        fail(c, "Error: At least two points are required for interpolation!");
+        return -1.0;
+    }
     return interp_value(&c->E, nxt, nxt->cash, n1, gm + 1, gv + 1);
 }
 
@@ -271,6 +275,7 @@ static int expectation_at(ctx_t *c, const ms_pv *cur, ms_pv *nxt, int keep, doub
                 rhs += pr1 * ms_utility_marginal(E, nxt, c1) * ms_cashinhand_marginal(E, cur, nxt);
                 if (keep == 1) {
                     evf += pr1 * next_value(c, nxt);
+                    if (c->err[0]) return -1; /* egdst_solver.c:568 */
                     if (evf == -INFINITY) break;
                 }
             }

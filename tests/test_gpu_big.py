@@ -143,3 +143,67 @@ def test_batch_build_variants_of_the_stress_configs_equal_the_fixtures(name, wl)
         assert np.array_equal(sv.checksums(d), sd.checksums(d)), d
     sv.close()
     sd.close()
+
+
+def _solve_with_env(lib, m, P, env):
+    """a kept-history solve with environment switches of the library set for the duration of the solve (they are read at solve time)"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=True)
+        s.set_params(P)
+        s.solve(raise_on_error=False)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return s
+
+
+@pytest.mark.parametrize('a0', [0.0, -5.0])
+def test_c2_batch_build_on_the_path_the_bench_runs(a0):
+    """The headline batch is solved by the C2 build variant on kernels a 49-draw batch never reaches: k_grid_lds_cv at 512 threads and
+    64 VGPRs, and the throughput path of the envelope step (k_tp_* with its second tier for long lists).  1024 draws on exactly that
+    path -- asserted from the path's own counters -- against (i) the default build with the envelope step on k_envelope alone and the
+    general grid kernel's LDS form (another kernel for every phase): status, evaluation counts and the checksums of every cell of
+    every draw; (ii) the oracle, cell by cell, on the draws that give the slow paths most to do (left-over cells, regenerated guess
+    streams) and on failing draws, whose error texts must be the oracle's."""
+    from egdst_amd import examples
+    from oracle_harness import Oracle
+    nd = 1024
+    m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
+    P = workloads.c2()[1](nd)
+    lib_v = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS['C2'])
+    sv = _solve_with_env(lib_v, m, P, {})
+    tps = sv.tp_stats()
+    done, left = int(tps[:, 0].sum()), int(tps[:, 1].sum())
+    nt = m.descriptor()['T'] - m.descriptor()['t0'] + 1
+    assert done > 0.9 * nd * (nt - 1) and done + left == nd * (nt - 1), (done, left)   # the throughput path did the cells
+    sd = _solve_with_env(build.build_model(m), m, P, {'EGDST_ENV_TP': '0', 'EGDST_GRID_CV': '0'})
+    assert int(sd.tp_stats().sum()) == 0                                               # ... and the other side did not use it
+    st, ev = sv.status()[0], sv.evals()[1]
+    assert np.array_equal(st, sd.status()[0]) and np.array_equal(sv.status()[1], sd.status()[1])
+    assert np.array_equal(ev, sd.evals()[1])
+    for d in range(nd):
+        assert np.array_equal(sv.checksums(d), sd.checksums(d)), d
+        lv, tv = sv.dims(d)
+        ld, td = sd.dims(d)
+        assert np.array_equal(lv, ld) and np.array_equal(tv, td), d
+    sd.close()
+    # the oracle on the interesting draws
+    score = tps[:, 1].astype(np.int64) * 1000 + sv.regenerations().astype(np.int64)
+    pick = list(np.argsort(-score, kind='stable')[:24]) + list(np.nonzero(st != 0)[0][:16])
+    orc = Oracle(m)
+    for d in dict.fromkeys(int(x) for x in pick):
+        r = orc.solve(P[d])
+        assert (r.rc == 0) == (st[d] == 0), d
+        if r.rc:
+            assert lib_v.lib.egdst_strerror(int(st[d])).decode().strip() == r.err.strip(), d
+        else:
+            assert ev[d] == r.nevals, d
+        ln, th = sv.dims(d)
+        assert np.array_equal(ln, r.len) and np.array_equal(th, r.thlen), d
+        assert np.array_equal(sv.checksums(d), cell_sums(r)), d
+    sv.close()
