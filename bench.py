@@ -20,17 +20,21 @@ contributions are reduced with one RCCL all-reduce.  Rank 0 prints ONE JSON line
 value       = evaluations EXECUTED for the draws that solved (failed draws and the evaluations the device credits
               without executing -- include/egdst.h egdst_get_evals_credited -- are left out), all ranks, all timed
               steps / max-over-ranks wall time.  `evals_reference_per_step` is what the reference would count.
-roofline    = algorithmic table bytes per launch of the dominant kernel class / its mean HIP-event duration (events on the
-              group streams the kernels are launched on), against the 8 TB/s HBM3E peak; `traffic`, `valu_util`,
-              `valu_fp64_util`, `lds_GBps` from the rocprofv3 --pmc passes committed under profiles/ for this very
-              configuration (counters cannot be read from inside the process).  The path is NOT HBM-bound at these
-              sizes (SURVEY.md section 8d says so): the fraction is reported as it is, and `ceilings` says what does bind:
+roofline    = for the dominant kernel (largest total duration in the committed rocprofv3 trace of this configuration,
+              profiles/r04_kernel_stats_<key>.csv): the algorithmic table bytes of the cells one launch handles / its mean
+              HIP-event duration in one more solve of the last step's draws with ONE draw group (events on the launching stream,
+              the kernel alone on the GPU; `timed_step` holds the queue-inclusive figure of the 16-stream solve), against the
+              8 TB/s HBM3E peak; `traffic`, `valu_util`, `valu_fp64_util`, `lds_GBps` from the rocprofv3 --pmc passes committed
+              under profiles/ for this very configuration (counters cannot be read from inside the process); `step` = the
+              whole step: algorithmic bytes / ms_per_step, and the summed counter traffic of all its kernels.  The path is NOT
+              HBM-bound at these sizes (SURVEY.md section 8d says so): the fraction is reported as it is, and `ceilings` says
+              what does bind:
               `egm_only_evals_per_s` = the evaluations of the step / the summed device time of the grid kernel alone (what
               the step would deliver if the EGM evaluations were all there is), `pipeline_frac_of_egm_only` = value / that,
               and the issue-slot figures of the grid kernel from the counter passes.
 legs        = (N = 1) one warm-up and one timed step each of the per-GPU shares of the stress configurations BASELINE.json
-              names (C4 x 32 draws, C5 x 128 draws at full size) and of C2 on the surveyed credit limit a0 = -5 (4096 draws,
-              failures counted), each with its own roofline; (N > 1) `strong`: one timed step of the north_star's batches
+              names (C4 x 32 draws, C5 x 128 draws at full size) and of C2 with a0 = 0 (the headline of rounds 1-3; the headline is
+              now C2 on the surveyed credit limit a0 = -5), each with its own roofline; (N > 1) `strong`: one timed step of the north_star's batches
               (C5 x 1024, C4 x 256 draws) sharded over the N ranks.
 cpu_baseline= the CPU oracle (oracle/egdst_oracle.c, glibc math, gcc -O2) on a bounded sample of the same draws, timed in
               this run on the GPU box's host: one thread (`value`, `cores` = 1) and every core this process may use
@@ -134,60 +138,129 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def pmc_metrics(workload, ndraw, kernel):
-    """Counter-derived figures of `kernel` from the committed PMC passes of this configuration, or {}."""
-    try:
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_metrics.json')))
-        cfg = tj.get('%s_ndraw%d' % (workload, ndraw), {})
-        return cfg.get(kernel, {})
-    except (OSError, ValueError):
-        return {}
-
 CLASS_NAMES = ['probe', 'grid', 'k_envelope', 'regeneration', 'tp_prep', 'tp_sort0', 'tp_sort1', 'tp_walk0', 'tp_walk1']
-CLASS_KERNELS = [['k_probe'], ['k_grid_lds_cv', 'k_grid_lds', 'k_grid_wide', 'k_grid', 'k_grid_lds_n'], ['k_envelope'], ['k_fixup'], ['k_tp_prep'], ['k_tp_sort'],
-                 ['k_tp_sort'], ['k_tp_walk'], ['k_tp_walk']]
+# the kernels of a period (profile classes of each; the two stages of k_tp_sort / k_tp_walk are one kernel) and what a launch of
+# theirs covers: 'cells' = every cell of the group (dense kernels), 'left' = the cells the throughput path left to k_envelope,
+# 'regen' = the guess streams k_fixup regenerated
+KERNELS = [('k_probe', ['k_probe'], [0], 'cells'),
+           ('grid', ['k_grid_lds_cv', 'k_grid_lds', 'k_grid_wide', 'k_grid'], [1], 'cells'),
+           ('k_envelope', ['k_envelope'], [2], 'left'),
+           ('k_fixup', ['k_fixup'], [3], 'regen'),
+           ('k_tp_prep', ['k_tp_prep'], [4], 'cells'),
+           ('k_tp_sort', ['k_tp_sort', 'k_tp_sort_big'], [5, 6], 'cells'),
+           ('k_tp_walk', ['k_tp_walk', 'k_tp_walk_big'], [7, 8], 'cells')]
+TRACE_ROUND = 'r04'
 
 
-def pmc_for(workload, ndraw, cls, small=False):
-    """(kernel name, counter figures) of a profile class from the committed PMC passes of this configuration"""
-    cands = CLASS_KERNELS[cls]
+def trace_stats(key):
+    """{kernel base name: (calls, total ns, average ns)} from the committed rocprofv3 --kernel-trace --stats summary of this
+    configuration (profiles/<round>_kernel_stats_<key>.csv), or {}"""
+    import csv
+    f = os.path.join(ROOT, 'profiles', '%s_kernel_stats_%s.csv' % (TRACE_ROUND, key))
+    out = {}
+    try:
+        for row in csv.DictReader(open(f)):
+            out[row['Name'].split('(')[0]] = (int(row['Calls']), float(row['TotalDurationNs']), float(row['AverageNs']))
+    except (OSError, KeyError, ValueError):
+        return {}, None
+    return out, os.path.relpath(f, ROOT)
+
+
+def roofline_record(key, kms, klaunch, algbytes, evals_step, value, ms_step, cells, left, regen, small=False, serial_ms=None, serial_launch=None):
+    """The `roofline` object of one configuration.
+
+    key: '<workload>_ndraw<N>' -- names the committed trace (profiles/r04_kernel_stats_<key>.csv) and counters (pmc_metrics.json).
+    Dominant kernel: the one with the largest total duration in that trace (deterministic: a committed file), else in the one-group
+    HIP-event profile of this run.  Its `achieved` = the algorithmic bytes of the cells ONE LAUNCH of it handles / its average launch
+    duration, both taken from the one-group solve of this run (every kernel with the GPU to itself: HIP events on the launching
+    stream bracket the kernel, not its wait behind fifteen other groups); `timed_step` holds the queue-inclusive figure of the
+    16-stream step beside it and `trace_avg_launch_ms` the committed trace's.  `step` is the whole step against the same peak."""
+    tr, tr_file = ({}, None) if small else trace_stats(key)
+    pmc_cfg = {}
     if not small:
-        for cand in cands:
-            pm = pmc_metrics(workload, ndraw, cand)
-            if pm:
-                return cand, pm
-    return cands[0], {}
+        try:
+            pmc_cfg = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_metrics.json'))).get(key, {})
+        except (OSError, ValueError):
+            pmc_cfg = {}
+    per = {}
+    for name, knames, classes, covers in KERNELS:
+        ms16, n16 = sum(kms[c] for c in classes), sum(int(klaunch[c]) for c in classes)
+        ms1 = sum(serial_ms[c] for c in classes) if serial_ms is not None else None
+        n1 = sum(int(serial_launch[c]) for c in classes) if serial_launch is not None else 0
+        tcalls = sum(tr[k][0] for k in knames if k in tr)
+        tns = sum(tr[k][1] for k in knames if k in tr)
+        pm = next((pmc_cfg[k] for k in knames if k in pmc_cfg), {})
+        kname = next((k for k in knames if k in tr or k in pmc_cfg), knames[0])
+        per[name] = dict(kernel=kname, covers=covers, ms16=ms16, n16=n16, ms1=ms1, n1=n1, trace_calls=tcalls, trace_ns=tns, pm=pm)
+    if any(v['trace_ns'] for v in per.values()):
+        dom, dom_by = max(per, key=lambda k: per[k]['trace_ns']), 'largest total duration in ' + tr_file
+    elif serial_ms is not None:
+        dom, dom_by = max(per, key=lambda k: per[k]['ms1'] or 0.0), 'largest device time in the one-group solve of this run (no committed trace of this configuration)'
+    else:
+        dom, dom_by = max(per, key=lambda k: per[k]['ms16']), 'largest summed HIP-event time of the last step'
+    d = per[dom]
+    # share of the step's algorithmic bytes the dominant kernel's launches handle: all cells (dense kernels), or the cells / streams
+    # it was actually given
+    share = {'cells': 1.0, 'left': left / max(cells, 1), 'regen': regen / max(2 * cells, 1)}[d['covers']]
+    bytes_dom = algbytes * share
 
-
-def roofline_record(workload, ndraw, kms, klaunch, algbytes, evals_step, value, small=False, serial_ms=None):
-    """the `roofline` object of one configuration from the HIP-event profile of its last solve.  serial_ms: the same classes
-    from a solve of the same handle with ONE draw group (every kernel has the GPU to itself: no concurrent streams)."""
-    # the dominant KERNEL: the two stages of k_tp_sort / k_tp_walk are one kernel each (classes 5+6, 7+8)
-    kernels = [[0], [1], [2], [3], [4], [5, 6], [7, 8]]
-    tot = [sum(kms[c] for c in k) for k in kernels]
-    domk = kernels[int(np.argmax(tot))]
-    dom = domk[0]
-    dom_ms, dom_launches = sum(kms[c] for c in domk), sum(klaunch[c] for c in domk)
-    avg_launch_s = (dom_ms / max(dom_launches, 1)) * 1e-3
-    bytes_per_launch = algbytes / max(dom_launches, 1)
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    dom_kernel, pm = pmc_for(workload, ndraw, dom, small)
-    _, pg = pmc_for(workload, ndraw, 1, small)
+    def rate(ms, n):
+        if not ms or not n:
+            return None, None, None
+        avg = ms / n
+        ach = bytes_dom / n / (avg * 1e-3) / 1e9
+        return avg, bytes_dom / n, ach
+    avg1, bpl1, ach1 = rate(d['ms1'], d['n1'])
+    avg16, bpl16, ach16 = rate(d['ms16'], d['n16'])
+    achieved, avg, bpl = (ach1, avg1, bpl1) if ach1 is not None else (ach16, avg16, bpl16)
+    pm = d['pm']
+    # whole step: algorithmic bytes and, from the counter passes, the HBM-side traffic of all kernels of a step
+    traffic_step = None
+    if pmc_cfg and any(v['pm'] for v in per.values()):
+        traffic_step = 0.0
+        for v in per.values():
+            if v['pm'] and v['n16']:
+                traffic_step += v['pm']['hbm_bytes_per_launch'] * v['n16']
     grid_alone = float(serial_ms[1]) if serial_ms is not None else None
     egm_only = evals_step / (grid_alone * 1e-3) if grid_alone else None
+    pg = per['grid']['pm']
+    dense_sum = sum(float(serial_ms[c]) for c in (0, 1, 4, 5, 6, 7, 8)) if serial_ms is not None else None
     return {'bound': 'hbm', 'bound_note': 'reported against HBM as the contract asks; the path is latency / issue bound, see ceilings',
-            'kernel': dom_kernel, 'kernel_class': '+'.join(CLASS_NAMES[c] for c in domk), 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-            'frac': achieved / 8000.0, 'traffic': pm.get('hbm_bytes_per_launch'),
-            'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches': int(dom_launches),
+            'kernel': d['kernel'], 'kernel_class': dom, 'dominant_by': dom_by,
+            'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': (achieved / 8000.0) if achieved is not None else None,
+            'traffic': pm.get('hbm_bytes_per_launch'),
+            'algorithmic_bytes_per_launch': bpl, 'avg_launch_ms': avg, 'launches': int(d['n1'] or d['n16']),
+            'measured': 'HIP events around the launches of one more solve of the same draws with ONE draw group (the kernel has the GPU to itself), right after the timed region',
+            'share_of_step_bytes': share,
+            'timed_step': {'note': 'the same kernel in the 16-stream step after the timed region: HIP events on the group streams, the wait in the hardware queue included',
+                           'avg_launch_ms': avg16, 'launches': int(d['n16']), 'achieved': ach16},
+            'trace_avg_launch_ms': (d['trace_ns'] / d['trace_calls'] * 1e-6) if d['trace_calls'] else None,
             'valu_util': pm.get('valu_util'), 'valu_fp64_util': pm.get('valu_fp64_util'), 'lds_GBps': pm.get('lds_GBps'),
             'wave_cycles_waiting_frac': pm.get('wave_cycles_waiting_frac'), 'counters_from': pm.get('source'),
+            'step': {'algorithmic_bytes': float(algbytes), 'ms_per_step': ms_step, 'achieved': algbytes / (ms_step * 1e-3) / 1e9,
+                     'frac': algbytes / (ms_step * 1e-3) / 1e9 / 8000.0, 'traffic_bytes': traffic_step,
+                     'traffic_over_algorithmic': (traffic_step / algbytes) if (traffic_step and algbytes) else None,
+                     'traffic_GBps': (traffic_step / (ms_step * 1e-3) / 1e9) if traffic_step else None, 'unit': 'GB/s',
+                     'note': 'traffic_bytes = sum over the kernels of (FETCH_SIZE + WRITE_SIZE per launch in the committed counter passes) x this run\'s launches'},
             'ceilings': {'note': 'egm_only: the evaluations of a step / the device time of the grid kernel when it has the GPU to itself '
                                  '(one draw group, no concurrent streams); kernel_ms_one_group: every class measured that way',
                          'egm_only_evals_per_s': egm_only,
                          'pipeline_frac_of_egm_only': (value / egm_only) if egm_only else None,
                          'kernel_ms_one_group': {n: float(v) for n, v in zip(CLASS_NAMES, serial_ms)} if serial_ms is not None else None,
+                         'dense_kernels_ms_one_group': dense_sum,
+                         'step_over_dense_one_group': (ms_step / dense_sum) if dense_sum else None,
                          'grid_kernel_issue_util': pg.get('valu_util'), 'grid_kernel_fp64_util': pg.get('valu_fp64_util'),
                          'grid_kernel_fp64_share_of_valu': (pg['valu_fp64_util'] / pg['valu_util']) if pg.get('valu_util') else None}}
+
+
+def profiled_step(solver):
+    """one more solve of the handle's current draws with HIP events around every launch, OUTSIDE every timed region (the events
+    are created when first recorded: inside a timed step that cost would be in `value`)"""
+    solver.set_profile(True)
+    solver.solve(raise_on_error=False)
+    out = solver.profile()
+    solver.set_profile(False)
+    return out
 
 
 def serial_profile(solver):
@@ -197,9 +270,10 @@ def serial_profile(solver):
     solver.set_groups(1)
     solver.set_profile(True)
     solver.solve(raise_on_error=False)
-    ms = solver.profile()[0]
+    ms, launches, _ = solver.profile()
+    solver.set_profile(False)
     solver.set_groups(groups)
-    return ms
+    return ms, launches
 
 
 def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None, chunk=None, sync=None, counters_as=None):
@@ -219,8 +293,6 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
     solver = runtime.Solver(lib, desc, ndraw=chunk, keep_history=False)
     rec = {}
     for timed in (False, True):
-        if timed:
-            solver.set_profile(True)
         if sync:
             sync()
         torch.cuda.synchronize()
@@ -242,8 +314,10 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
             sync()
         dt = time.perf_counter() - t0
         rec = {'dt': dt, 'ev_ref': ev_ref, 'ev_exec': ev_exec, 'nfail': nfail}
-    kms, klaunch, algbytes = solver.profile()   # of the last chunk's solve
-    serial_ms = serial_profile(solver)
+    kms, klaunch, algbytes = profiled_step(solver)   # the last chunk's draws once more, HIP events on, outside the timed step
+    tps, regen = solver.tp_stats(), solver.regenerations()
+    nst, nt = lib.info.nst, desc['T'] - desc['t0'] + 1
+    serial_ms, serial_launch = serial_profile(solver)
     solver.close()
     value = rec['ev_exec'] / rec['dt']
     out = {'workload': label or '%s x %d draws' % (workload, ndraw), 'ndraw': ndraw, 'chunk': chunk, 'build_flags': flags,
@@ -252,8 +326,9 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
            'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
            'config': 'T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (desc['T'], desc['ngridm'], desc['ny'], lib.info.nd,
                                                                                    lib.info.nst, desc['a0'], desc['mmax'])}
-    out['roofline'] = roofline_record(counters_as or workload, chunk, kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value,
-                                      serial_ms=serial_ms)
+    out['roofline'] = roofline_record('%s_ndraw%d' % (counters_as or workload, chunk), kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value,
+                                      rec['dt'] * 1e3 / max(len(plan), 1), chunk * nst * nt, int(tps[:, 1].sum()) if lib.info.nd > 1 else chunk * nst * nt,
+                                      int(regen.sum()), serial_ms=serial_ms, serial_launch=serial_launch)
     out['_raw'] = rec
     return out
 
@@ -275,7 +350,7 @@ def main():
     ap.add_argument('--no-single-solve', action='store_true', help='skip the one-draw latency legs (profiling runs)')
     ap.add_argument('--no-extras', action='store_true', help='skip the copy-peak, export and estimation legs')
     ap.add_argument('--rehearse-legs', action='store_true', help='N > 1: the strong-scaling sub-records on reduced batches (C5 x 32, C4 x 8 draws): a plumbing rehearsal on one card, not a result')
-    ap.add_argument('--no-legs', action='store_true', help='skip the legs of the stress configurations (C4 x 32, C5 x 128, C2 a0=-5; N > 1: the strong-scaling batches)')
+    ap.add_argument('--no-legs', action='store_true', help='skip the legs of the stress configurations (C4 x 32, C5 x 128, C2 a0=0; N > 1: the strong-scaling batches)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -396,14 +471,15 @@ def main():
     tot = np.zeros(4, dtype=np.int64)
     for s in range(args.warmup, nsteps_all):
         if solver:
-            if s == nsteps_all - 1:
-                solver.set_profile(True)   # HIP events around the launches of the LAST timed step (egdst_get_profile reports the last solve)
             tot += np.array(run_step(s), dtype=np.int64)
     sync_all()
     dt = time.perf_counter() - t0
 
-    kms, klaunch, algbytes = solver.profile() if solver else (np.zeros(9), np.zeros(9, dtype=np.int32), 0)   # of the LAST solve
-    serial_ms = serial_profile(solver) if (solver and rank == 0 and world == 1 and not args.no_extras) else None
+    # the last step's draws once more with HIP events around every launch (16 streams), then with one draw group: outside the timed region
+    kms, klaunch, algbytes = profiled_step(solver) if solver else (np.zeros(9), np.zeros(9, dtype=np.int32), 0)
+    tps_last = solver.tp_stats() if solver else np.zeros((1, 2))
+    regen_last = int(solver.regenerations().sum()) if solver else 0
+    serial_ms, serial_launch = serial_profile(solver) if (solver and rank == 0 and world == 1 and not args.no_extras) else (None, None)
     # ---- final objective reduce: the only collective of the path (RCCL over xGMI when world > 1) -----------------
     last = obj[nsteps_all - 1, :mine_n, 0] if mine_n else torch.zeros(0, dtype=torch.float64, device='cuda')
     okmask = ~torch.isnan(last)
@@ -472,10 +548,12 @@ def main():
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
             'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},
             'envelope_cells_by_throughput_path': main_extra['envelope_cells_by_throughput_path'],
-            'roofline': roofline_record(args.workload, chunk, kms, klaunch, algbytes, ev_exec_all / args.steps / max(world * nchunks, 1),
-                                        ev_exec_all / dt_max, small=args.small, serial_ms=serial_ms),
+            'roofline': roofline_record('%s_ndraw%d' % (args.workload, chunk), kms, klaunch, algbytes, ev_exec_all / args.steps / max(world * nchunks, 1),
+                                        ev_exec_all / dt_max, ms_step / max(nchunks, 1), chunk * lib.info.nst * (desc['T'] - desc['t0'] + 1),
+                                        int(tps_last[:, 1].sum()) if lib.info.nd > 1 else chunk * lib.info.nst * (desc['T'] - desc['t0'] + 1),
+                                        regen_last, small=args.small, serial_ms=serial_ms, serial_launch=serial_launch),
         }
-        one = host_draws[-1][:1] if mine_n else None
+        one = np.asarray(model.param_vector(), dtype=np.float64)[None] if mine_n else None   # fixed parameters: comparable from run to run
         if not args.no_single_solve and world == 1 and mine_n:
             # single-solve latency (one draw): the "full backward-induction wall time" half of the metric
             s1 = runtime.Solver(lib, desc, ndraw=1, keep_history=False)
@@ -498,19 +576,19 @@ def main():
                 out['export_bytes'] = int(sol.len.sum()) * 24 + int(sol.thlen.sum()) * 16
                 s2.close()
         if not args.no_extras and not args.no_single_solve and world == 1 and args.workload == 'C2' and not args.small:
-            # SURVEY.md section 8d pins C2 on the shipped credit limit a0=-5 (the survey's probe: 1 180 889 evaluations); the
-            # headline runs a0=0 because with a0=-5 the reference algorithm itself writes a non-finite row at it=4
-            from egdst_amd import examples
-            m5 = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=-5)
-            s5 = runtime.Solver(build.build_model(m5), m5.descriptor(), ndraw=1, keep_history=False)
-            s5.set_params(m5.param_vector()[None])
-            s5.solve(raise_on_error=False)
-            t1 = time.perf_counter()
-            for _ in range(3):
-                s5.solve(raise_on_error=False)
-            out['c2_shipped_a0_minus5'] = {'single_solve_ms': (time.perf_counter() - t1) / 3 * 1e3, 'evals': int(s5.evals()[0]),
-                                           'status': int(s5.status()[0][0])}
-            s5.close()
+            # the other one-draw latencies the verdicts follow: C2 with a0 = 0 (the configuration of rounds 1-3) and C3
+            def one_solve(mk):
+                mm = mk()
+                ss = runtime.Solver(build.build_model(mm), mm.descriptor(), ndraw=1, keep_history=False)
+                ss.set_params(mm.param_vector()[None])
+                ss.solve(raise_on_error=False)
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    ss.solve(raise_on_error=False)
+                r_ = {'single_solve_ms': (time.perf_counter() - t_) / 3 * 1e3, 'evals': int(ss.evals()[0]), 'status': int(ss.status()[0][0])}
+                ss.close()
+                return r_
+            out['single_solve_other'] = {'c2_a0_0': one_solve(lambda: workloads.c2(a0=0)[0]), 'c3': one_solve(lambda: workloads.c3()[0])}
         if not args.no_extras and world == 1:
             # measured streaming-copy rate of this box (read + write), the practical HBM ceiling beside the 8 TB/s spec
             a = torch.empty(1 << 28, dtype=torch.float64, device='cuda')   # 2 GiB
@@ -535,9 +613,9 @@ def main():
             legs = {}
             legs['C4x32'] = timed_leg('C4', 32, label='C4 x 32 draws: the per-GPU share of BASELINE configs[3] (256 draws over 8 GPUs)')
             legs['C5x128'] = timed_leg('C5', 128, label='C5 x 128 draws at full size: the per-GPU share of BASELINE configs[4] (1024 draws over 8 GPUs)')
-            m5 = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=-5)
-            legs['c2_a0_minus5_batch'] = timed_leg('C2', args.ndraw, model=m5, params=host_draws[-1], counters_as='C2a0m5',
-                                                   label='C2 with the shipped credit limit a0=-5 (SURVEY section 8d), the same %d draws' % args.ndraw)
+            m0 = workloads.c2(a0=0)[0]
+            legs['c2_a0_0_batch'] = timed_leg('C2', args.ndraw, model=m0, params=host_draws[-1], counters_as='C2a0',
+                                              label='C2 with a0=0 (the headline configuration of rounds 1-3), the same %d draws' % args.ndraw)
             for v in legs.values():
                 v.pop('_raw', None)
             out['legs'] = legs

@@ -966,6 +966,30 @@ static __device__ __forceinline__ int eg_second_bracket(double x, int i, double 
     return (x < m2) ? 0 : ((x >= mlast2) ? n1 - 3 : i - 1);
 }
 
+// eg_bracket(x, g, n, 0) on a NON-DECREASING column without NaN (the caller checked the order): bxsearch_common (egdst_lib.c:136-166)
+// returns 0 below g[1], n-2 from g[n-2] on, and between them the last row that is not above x -- on an ordered column that is
+// "the last row i in [1, n-2] with g[i] <= x, or 0", however it is found.  Here: the branch-free form of the bisection -- the
+// range [base, base+len) shrinks by len/2 per step whatever the comparison says, so every lane makes the SAME number of steps (n
+// is uniform over the workgroup) and a step is one LDS read, one compare and one select.  The reference's loop compiled to ~22
+// instructions per step, 13 of them scalar bookkeeping of the lanes that had finished (profiles/r04_*: k_grid_lds_cv 5876
+// instructions, 2981 scalar).  A NaN x fails every comparison of the reference and its bisection runs up to row n-3: the same here.
+template <class P> static __device__ __forceinline__ int eg_last_le(double x, P g, int nrows)  // last row of [0, nrows) with g <= x, or 0
+{
+    int base = 0;
+    for (int len = nrows; len > 1;) {
+        const int half = len >> 1;
+        const double gj = g[base + half];
+        base = (gj <= x) ? base + half : base;
+        len -= half;
+    }
+    return base;
+}
+template <class P> static __device__ __forceinline__ int eg_bracket_sorted(double x, P g, int n)
+{
+    const int i = eg_last_le(x, g, n - 1);  // rows 0 .. n-2
+    return (x != x) ? n - 3 : i;
+}
+
 // eg_bracket(x, g, n, 0) on a NON-DECREASING column, starting from a hint: the bracket of a neighbouring asset point for the
 // same next state and shock node.  The search returns the last row i in [1, n-3] with g[i] <= x (0 below g[1], n-2 from
 // g[n-2] on), which on an ordered column is unique -- however it is found.  Cash-in-hand moves by less than a table row or two
@@ -996,14 +1020,15 @@ template <class P> static __device__ __forceinline__ int eg_bracket_near(double 
 // eg_term + eg_next_value for keep == 1 with the M column in LDS and one search (see above).  ibr: nullptr, or in: the
 // bracket of the neighbouring asset point (< 0: none), out: this point's.
 // TT: Tab (C and V in global memory) or TabL (staged in LDS as well, k_grid_lds_cv)
+// sorted: the staged column is known to be in order (the callers' fast path): the branch-free search
 template <class TT>
 static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_ldsd *M, const TT &t, const ms_pv *cur, ms_pv *nxt,
-                                                     double pr1, double *t_rhs, double *t_evf, int *ibr = nullptr)
+                                                     double pr1, double *t_rhs, double *t_evf, int *ibr = nullptr, int sorted = 0)
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const double x = nxt->cash;
     const int n1 = t.len;
-    const int i = (ibr && *ibr >= 0) ? eg_bracket_near(x, M, n1, *ibr) : eg_bracket(x, M, n1, 0);
+    const int i = (ibr && *ibr >= 0) ? eg_bracket_near(x, M, n1, *ibr) : (sorted ? eg_bracket_sorted(x, M, n1) : eg_bracket(x, M, n1, 0));
     if (ibr) *ibr = i;
     const double mlast = M[n1 - 1], mfirst = M[1];
     // rows i and i+1 of C and of V in ONE round of global reads: away from the table's ends valuefunc's bracket is the same
@@ -1047,28 +1072,24 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
 // is staged (a sampled index), the bracket search runs on the sample in LDS and is finished by log2(stride) steps in the
 // window of the global column between two samples (one or two cache lines) -- 3-5 dependent global loads per evaluation
 // instead of 2 x 16.  The column must be in order (k_sortcheck, once per table); `edge` holds M[1], M[2], M[len-2], M[len-1].
+// Both searches in the branch-free form of eg_last_le: the same number of steps on every lane (ns and stride are uniform); the
+// window's reads are the only global ones.
 static __device__ __forceinline__ int eg_bracket_sampled(double x, const eg_ldsd *S, int ns, int stride, const double *M, int n1,
                                                          const eg_ldsd *edge)
 {
-    if (x < edge[0]) return 0;
-    if (x >= edge[2]) return n1 - 2;
-    int lo = 0, hi = ns;  // S[0] = M[0] <= M[1] <= x
-    while (hi - lo > 1) {
-        const int mid = (hi + lo) >> 1;
-        if (S[mid] <= x)
-            lo = mid;
-        else
-            hi = mid;
+    const int k = eg_last_le(x, S, ns);  // last sample not above x (S[0] = M[0] <= M[1] <= x on the lanes whose result is used)
+    int base = k * stride;
+    const int zl = max(min(base + stride, n1 - 2) - 1, 0);  // M[base] <= x < M[zl + 1]: the last row of [base, zl] that is not above x
+    for (int len = stride; len > 1;) {
+        const int half = len >> 1, c = min(base + half, zl);
+        const double mj = M[c];
+        base = (mj <= x) ? c : base;
+        len -= half;
     }
-    int a = lo * stride, z = min(a + stride, n1 - 2);  // M[a] <= x < M[z]
-    while (z - a > 1) {
-        const int mid = (z + a) >> 1;
-        if (M[mid] <= x)
-            a = mid;
-        else
-            z = mid;
-    }
-    return a;
+    if (x != x) base = n1 - 3;  // (a NaN fails every comparison of the reference's bisection, which then runs up to row n-3)
+    if (x < edge[0]) base = 0;
+    if (x >= edge[2]) base = n1 - 2;
+    return base;
 }
 
 static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const eg_ldsd *S, int ns, int stride, const eg_ldsd *edge,
@@ -1341,10 +1362,10 @@ template <int PPL, bool CV = false> static __device__ __forceinline__ void eg_gr
                         TabL tl;
                         tl.M = M, tl.C = (const eg_ldsd *)LC + gl_off[nxt.ist], tl.V = (const eg_ldsd *)LV + gl_off[nxt.ist];
                         tl.TH = t.TH, tl.D = t.D, tl.len = t.len, tl.thlen = t.thlen;
-                        c1[j] = eg_term_lds(&E, M, tl, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr);
+                        c1[j] = eg_term_lds(&E, M, tl, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr, 1);
                     } else
                     c1[j] = (stride > 1) ? eg_term_sampled(&E, M, ns, stride, edge, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr)
-                                         : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr);
+                                         : eg_term_lds(&E, M, t, &cur, &nxt, pr1, &t_rhs, &t_evf, PPL > 1 ? &hint : nullptr, 1);
                     if (c1[j] > 0) {
                         rhs[j] += t_rhs;
                         evf[j] += t_evf;

@@ -1,8 +1,12 @@
 """BASELINE.json configs restated concretely + parameter-draw generators.
 
-C2 note: with the shipped credit limit a0=-5 the reference algorithm itself emits a non-finite
-consumption row at it=4 for T=60/ngridm=1000 (checked with the glibc oracle), so the T=60 config
-uses a0=0, for which every period is finite and monotone; the a0=-5 forms are covered at T=40.
+C2 is pinned by SURVEY.md §8(d) on the forms and values of model_retirement2.m, credit limit a0 = -5 included
+(egdst_examples/model_retirement2.m:36-41): that is `c2()`, the configuration bench.py's headline runs.  The default draw solves
+(1 180 889 evaluations, the survey's probe number); about 12 % of the 4096 perturbed draws of the batch do not -- the reference
+algorithm fails on them (stage 0 of adraw finds no savings with positive consumption; a guess stream that ends in the resend fixed
+point leaves a one-row table and the next period stops with "At least two points are required for interpolation!") and so do the
+oracle and the device, with the same texts.  `c2(a0=0)` is the easier parameterisation rounds 1-3 reported (1.5 % failing draws);
+it stays as a leg of the bench and as the configuration of most full-size fixtures.
 """
 from __future__ import annotations
 
@@ -21,9 +25,9 @@ def c1():
     return examples.deaton_sig(a0=0, mmax=50, t0=1, T=20, ngridm=100, ny=5), None
 
 
-def c2(ngridm=1000, T=60, ny=10):
-    """retirement2 forms, 2 discrete choices, T=60, 1000 grid points, 10 nodes (BASELINE configs[1])."""
-    m = examples.retirement_sig(T=T, ngridm=ngridm, ngridmax=10 * ngridm, nthrhmax=ngridm, ny=ny, a0=0)
+def c2(ngridm=1000, T=60, ny=10, a0=-5.0):
+    """retirement2 forms, 2 discrete choices, T=60, 1000 grid points, 10 nodes, a0=-5 (BASELINE configs[1])."""
+    m = examples.retirement_sig(T=T, ngridm=ngridm, ngridmax=10 * ngridm, nthrhmax=ngridm, ny=ny, a0=a0)
 
     def draws(ndraw, seed=20241):
         # params: duw, interest, wage, sig  -- draws over (duw, wage, sigma), interest fixed (SURVEY §8d C5 ranges)

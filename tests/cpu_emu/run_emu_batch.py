@@ -34,7 +34,7 @@ def run(model, P, keep_history, sanitize='address', env_bs=1, wave=1):
 
 
 if __name__ == '__main__':
-    m, gen = workloads.c2(ngridm=int(sys.argv[1]), T=int(sys.argv[2]), ny=5)
+    m, gen = workloads.c2(a0=0, ngridm=int(sys.argv[1]), T=int(sys.argv[2]), ny=5)
     P = gen(int(sys.argv[3]))
     for kh in (True, False):
         for r in run(m, P, kh, os.environ.get('EMU_SANITIZE', 'address')):

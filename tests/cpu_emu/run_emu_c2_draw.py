@@ -10,7 +10,7 @@ from oracle_harness import Oracle
 from parity import compare
 
 if __name__ == '__main__':
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(4096)
     text = codegen.generate_modelspec(m)
     d = os.path.join(build.MODELS_DIR, build.model_tag(m, text))

@@ -9,7 +9,7 @@ from egdst_amd import build, codegen, runtime, workloads
 from oracle_harness import Oracle
 
 if __name__ == '__main__':
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(1024)
     idx = [int(a) for a in sys.argv[1:]]
     text = codegen.generate_modelspec(m)

@@ -12,7 +12,7 @@ import estimation_case
 
 if __name__ == '__main__':
     san = os.environ.get('EMU_SANITIZE', 'address')
-    m, gen = workloads.c2(ngridm=60, T=10, ny=5)
+    m, gen = workloads.c2(a0=0, ngridm=60, T=10, ny=5)
     P = gen(5)
     text = codegen.generate_modelspec(m)
     d = os.path.join(build.MODELS_DIR, build.model_tag(m, text))

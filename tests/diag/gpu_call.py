@@ -5,7 +5,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 from oracle_harness import Oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m)
 P = gen(1)
 s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)

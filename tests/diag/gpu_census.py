@@ -11,7 +11,7 @@ a0 = float(sys.argv[1]) if len(sys.argv) > 1 else -5.0
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 var = sys.argv[3] if len(sys.argv) > 3 else 'batch'
 m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
-_, gen = workloads.c2()
+_, gen = workloads.c2(a0=0)
 P = gen(nd)
 flags = (workloads.BATCH_BUILD_FLAGS['C2'] if var == 'batch' else []) + ['-DEGDST_CENSUS']
 lib = build.build_model(m, extra_flags=flags)

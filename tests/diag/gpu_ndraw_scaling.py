@@ -5,7 +5,7 @@ sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads, examples
 cap = int(sys.argv[1])
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m)
 for nd in [int(a) for a in sys.argv[2:]]:
     P = gen(nd)

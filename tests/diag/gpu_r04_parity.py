@@ -34,7 +34,7 @@ def _oracle(args):
 if __name__ == '__main__':
     from egdst_amd import build, runtime, workloads
     m = _model()
-    _, gen = workloads.c2()
+    _, gen = workloads.c2(a0=0)
     P = gen(nd)
     flags = workloads.BATCH_BUILD_FLAGS['C2'] if var == 'batch' else []
     lib = build.build_model(m, extra_flags=flags)

@@ -5,7 +5,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 from oracle_harness import Oracle
 nsim = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m)
 P = gen(4)
 for rndtype in (0, 1):

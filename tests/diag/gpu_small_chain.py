@@ -5,7 +5,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for ngridm in [int(a) for a in sys.argv[2:]] or [50, 200, 1000]:
-    m, gen = workloads.c2(ngridm=ngridm, T=60)
+    m, gen = workloads.c2(a0=0, ngridm=ngridm, T=60)
     lib = build.build_model(m)
     s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
     s.set_params(gen(nd)); s.solve(raise_on_error=False)

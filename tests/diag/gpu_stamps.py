@@ -3,7 +3,7 @@ import sys, ctypes as C
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps', extra_flags=['-DEGDST_STAMPS'])
 P = gen(64)
 for draw in [int(a) for a in sys.argv[1:]] or (0, 1):

@@ -5,7 +5,7 @@ import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 import os
 variant = os.environ.get('EGDST_HIPCC_EXTRA', '')
 lib = build.build_model(m, build_dir='egdst_amd/_models/_stamps' + ''.join(c for c in variant if c.isalnum()), extra_flags=['-DEGDST_STAMPS', '-DEGDST_STAMPS5'])

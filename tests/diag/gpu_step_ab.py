@@ -6,7 +6,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 AB = len(sys.argv) > 2 and sys.argv[2] == 'ab'
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 P = gen(nd)
 ref = {}
 for name, extra, bdir in [('lanes', [], None)] + ([('wave', ['-DENV_LANE_STEP=0'], 'egdst_amd/_models/_c2_oldstep')] if AB else []):

@@ -7,7 +7,7 @@ from egdst_amd import build, runtime, workloads
 from oracle_harness import Oracle
 from parity import compare
 nd, nt = int(sys.argv[1]), int(sys.argv[2])
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS['C2'] if len(sys.argv) > 3 and sys.argv[3] == 'batch' else ())
 print('library:', lib.path)
 P = gen(nd)

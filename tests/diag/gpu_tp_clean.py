@@ -6,7 +6,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 flags = sys.argv[2:]
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m, extra_flags=flags)
 P = gen(nd)
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)

@@ -7,7 +7,7 @@ from egdst_amd import build, runtime, workloads
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 flags = sys.argv[3:]
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m, extra_flags=flags)
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False, rows_cap=int(os.environ.get('ROWS_CAP', '0')))
 s.set_params(gen(nd))

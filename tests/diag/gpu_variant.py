@@ -3,7 +3,7 @@ import sys, time, os
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 nd = int(sys.argv[2])
 P = gen(nd)
 lib = runtime.ModelLibrary(os.path.join(build.MODELS_DIR, sys.argv[1], 'libegdst.so'))

@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-m, gen = workloads.c2()
+m, gen = workloads.c2(a0=0)
 lib = build.build_model(m)
 nd = int(sys.argv[1])
 P = gen(nd)

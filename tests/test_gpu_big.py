@@ -103,7 +103,7 @@ def test_batch_build_variant_equals_the_fixture_and_the_default_build():
     for fewer registers).  Same source, same results: draw 0 against the glibc fixture, 48 perturbed draws against the
     default build -- status, evaluation counts and the checksums of every cell."""
     g = load('C2')
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     flags = workloads.BATCH_BUILD_FLAGS['C2']
     P = np.concatenate([m.param_vector()[None], gen(48)])
     lib_v = build.build_model(m, extra_flags=flags)
@@ -174,7 +174,7 @@ def test_c2_batch_build_on_the_path_the_bench_runs(a0):
     from oracle_harness import Oracle
     nd = 1024
     m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
-    P = workloads.c2()[1](nd)
+    P = workloads.c2(a0=0)[1](nd)
     lib_v = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS['C2'])
     sv = _solve_with_env(lib_v, m, P, {})
     tps = sv.tp_stats()

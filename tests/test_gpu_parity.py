@@ -34,7 +34,7 @@ def gpu_solve(model, params=None, keep_history=True):
 
 SCALED = {
     'C1': lambda: workloads.c1()[0],
-    'C2': lambda: workloads.c2()[0],
+    'C2': lambda: workloads.c2(a0=0)[0],
     'C2_a0neg_T60': lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10),
     'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
     # 3 x 1400 points do not fit the LDS stream buffers: exercises the global-memory sort and walk
@@ -105,7 +105,7 @@ def test_class_surface_solve_and_sim():
 
 
 def test_batched_draws_equal_single_draw_solves():
-    m, gen = workloads.c2(ngridm=300, T=40)
+    m, gen = workloads.c2(a0=0, ngridm=300, T=40)
     P = gen(12)
     orc = Oracle(m)
     for keep in (True, False):
@@ -124,7 +124,7 @@ def test_batched_draws_equal_single_draw_solves():
 def test_full_size_batch_properties():
     """C2 at full size, 64 draws: every draw succeeds or fails as in the oracle (about 1 % of the parameter draws break
     the reference algorithm itself), eval counts equal the oracle's, grids monotone."""
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(64)
     s = gpu_solve(m, P, keep_history=True)
     st, _ = s.status()
@@ -156,14 +156,14 @@ def test_errors_are_reported_not_hidden():
         s.solve(raise_on_error=True)
 
 
-DEGENERATE = (67, 9, 771)   # draws of workloads.c2() on which the reference algorithm itself breaks down
+DEGENERATE = (67, 9, 771)   # draws of workloads.c2(a0=0) on which the reference algorithm itself breaks down
 
 
 def test_degenerate_draws_fail_like_the_oracle_with_pingpong_tables():
     """Draws whose guess stream re-bases at every point end in a one-row table; the reference then reads one row
     past the table's end and finds zeros (fresh matrix per period).  With two ping-pong periods the device must
     zero the rows past the new length to see the same: status, failing period and message equal the oracle's."""
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(1024)[list(DEGENERATE) + [0]]
     orc = Oracle(m)
     refs = [orc.solve(p) for p in P]
@@ -183,7 +183,7 @@ def test_draw_groups_and_compact_capacity_do_not_change_results():
     """Grouping draws on concurrent streams and the compact physical row capacity (with the exact redo of the
     draws that overflow it) are layout and scheduling choices only: per-draw status, evaluation counts,
     objective values and exported cells are bit-identical to the plain handle's."""
-    m, gen = workloads.c2(ngridm=300, T=30)
+    m, gen = workloads.c2(a0=0, ngridm=300, T=30)
     P = gen(24)
     lib = build.build_model(m)
     base = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=True)
@@ -210,7 +210,7 @@ def test_draws_with_many_monotone_pieces_bit_exact():
     """C2 draws with a high disutility of work fold the worker's choice list into dozens of monotone pieces: the
     secondary envelope then walks 20-50 functions, which exercises the wave-cooperative generic step (a function per
     lane, the reference's tie rules) and the range shortcuts of the rank-merge sort.  Tables bit for bit."""
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(64)[[57, 13, 11, 37]]
     s = gpu_solve(m, P, keep_history=True)
     orc = Oracle(m)
@@ -228,7 +228,7 @@ def test_history_based_schedule_does_not_change_results():
     (egdst_set_adaptive); solves with and without it must give the same per-draw status, evaluation counts and objective
     values.  (The draws that used to dominate -- the resend fixed point, ~9000 sequential calls -- are fast-forwarded
     since round 2 and no longer register as work: their credited evaluations are checked instead.)"""
-    m, gen = workloads.c2()
+    m, gen = workloads.c2(a0=0)
     P = gen(1024)[[0, 771, 3, 982, 5, 7, 11, 13]]
     lib = build.build_model(m)
     s = runtime.Solver(lib, m.descriptor(), ndraw=len(P), keep_history=False)
@@ -238,7 +238,9 @@ def test_history_based_schedule_does_not_change_results():
     first = (s.status()[0].copy(), s.evals()[1].copy(), s.objective().copy())
     cred = s.evals_credited()
     assert cred[1] > 50000 and cred[3] > 50000 and cred[0] == 0          # the two degenerate draws were fast-forwarded
-    assert first[0][1] == 15 and first[0][3] == 15 and first[0][0] == 0
+    # (their guess streams leave a one-row table; the next period stops in valuefunc's linter_extrap, egdst_lib.c:183 -- until round 4
+    #  oracle and device missed that check, went on with the one-row table and failed later with error 15)
+    assert first[0][1] == 10 and first[0][3] == 10 and first[0][0] == 0
     assert s.work()[1] < 1000 and s.work()[3] < 1000
     for _ in range(2):
         s.solve(raise_on_error=False)
@@ -252,7 +254,7 @@ def test_history_based_schedule_does_not_change_results():
 
 TP_CASES = {
     'retirement2': lambda: examples.retirement2(),
-    'C2': lambda: workloads.c2()[0],
+    'C2': lambda: workloads.c2(a0=0)[0],
     'C2_a0neg_T60': lambda: examples.retirement2(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10),
     'occ3_n400': lambda: examples.occ3(ngridm=400, ngridmax=4000, nthrhmax=400, ny=15),
     'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5),
@@ -296,7 +298,7 @@ def test_throughput_envelope_path_in_a_batch_with_failing_draws(monkeypatch):
     through k_envelope alone (EGDST_ENV_TP=0): status, failing period, evaluation counts, objective and -- for every draw
     -- the checksums of all cells are identical; a sample of the draws equals the oracle's tables bit for bit, and the
     draws on which the reference algorithm breaks down fail with the oracle's message."""
-    m, gen = workloads.c2(ngridm=300, T=30)
+    m, gen = workloads.c2(a0=0, ngridm=300, T=30)
     P = gen(600)
     lib = build.build_model(m)
     res = {}
@@ -616,7 +618,7 @@ def test_estimation_step_on_device(rndtype):
     oracle fed with the host replay of the same uniforms: counts exact, means 1e-13, objective 1e-11; a draw that fails to
     solve has a NaN objective."""
     import estimation_case
-    m, gen = workloads.c2(ngridm=300, T=30)
+    m, gen = workloads.c2(a0=0, ngridm=300, T=30)
     P = gen(1024)[[0, 1, 2, 3, 5, 8, 13, 771]]
     s = gpu_solve(m, P)
     rng = np.random.default_rng(5)
@@ -755,7 +757,7 @@ def test_walk_variants_agree_on_a_batch(monkeypatch):
     after the walk (ENV_CDEFER) -- the default build -- against the build with env_step_wave and the copy inside the batches
     (-DENV_LANE_STEP=0 -DENV_CDEFER_ON=0): 600 draws of C2 at ngridm=300, T=30, through the throughput path and through
     k_envelope alone: status, failing period, evaluation counts, objective and the checksums of every cell of a sample of draws."""
-    m, gen = workloads.c2(ngridm=300, T=30)
+    m, gen = workloads.c2(a0=0, ngridm=300, T=30)
     P = gen(600)
     res = {}
     for name, flags in (('default', []), ('old', ['-DENV_LANE_STEP=0', '-DENV_CDEFER_ON=0'])):

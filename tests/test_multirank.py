@@ -49,7 +49,7 @@ def _worker(rank, world, port, ndraw, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from egdst_amd import workloads
     from oracle_harness import Oracle
-    m, gen = workloads.c2(ngridm=40, T=6, ny=3)
+    m, gen = workloads.c2(a0=0, ngridm=40, T=6, ny=3)
     P = gen(ndraw)
     lo, hi = parallel.shard_bounds(ndraw, world, rank)
     orc = Oracle(m)
@@ -71,7 +71,7 @@ def test_two_ranks_reduce_equals_single_process():
     from egdst_amd import workloads
     from oracle_harness import Oracle
     ndraw = 5
-    m, gen = workloads.c2(ngridm=40, T=6, ny=3)
+    m, gen = workloads.c2(a0=0, ngridm=40, T=6, ny=3)
     orc = Oracle(m)
     ref = np.array([orc.solve(p).V[0, 0, 1] for p in gen(ndraw)])
     with socket.socket() as s:

@@ -101,7 +101,9 @@ def test_solution_import_serves_simulator_and_accessor(args):
 @pytest.mark.parametrize('args,env', [
     (['retirement2', 'T=8, ngridm=200, nthrhmax=200'], {}),                         # walks cut into segments (four walking waves)
     (['occ3', 'T=6, ngridm=30, ngridmax=100'], {'EGDST_TP_SORT_LKCAP': '16'}),       # sampled key index, permutation through global memory
-    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # streams beyond the walk's LDS: left to k_envelope
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIG': '0'}),   # streams beyond the walk's LDS: left to k_envelope
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # ... done by the second tier of stage 1 (k_tp_sort_big, k_tp_walk_big)
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIGCAP': '52'}),  # ... some by the second tier, the longest by k_envelope
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LONG': '2', 'EGDST_TP_SORT_LKCAP': '16'}),  # walks over global memory (k_tp_walk_g)
 ])
 def test_throughput_path_of_the_envelope_step(args, env):
@@ -115,9 +117,11 @@ def test_throughput_path_of_the_envelope_step(args, env):
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'ok=True' in r.stdout and 'max_rel=0.00e+00' in r.stdout, r.stdout + r.stderr[-2000:]
     done, left = eval(r.stdout.split('tp done/left')[1].strip())
-    assert done + left > 0 and (done > 0 or 'EGDST_TP_LKCAP' in env), r.stdout
-    if env.get('EGDST_TP_LKCAP'):
+    assert done + left > 0 and (done > 0 or env.get('EGDST_TP_BIG') == '0'), r.stdout
+    if env.get('EGDST_TP_LKCAP') and (env.get('EGDST_TP_BIG') == '0' or env.get('EGDST_TP_BIGCAP')):
         assert left > 0
+    if env.get('EGDST_TP_LKCAP') and env.get('EGDST_TP_BIG') != '0':
+        assert done > 0   # (with a 40-point budget the regular launch completes next to nothing: these are the second tier's)
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
 
 
@@ -138,7 +142,9 @@ def test_several_asset_points_per_lane_with_neighbour_hinted_search(args, lds):
 
 def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
     """Full-size C2, a draw on which the reference algorithm degenerates (one-row table at it=27): with ping-pong
-    tables the failure must be the oracle's (error 15 at it=26), not a success built on stale rows."""
+    tables the failure must be the oracle's, not a success built on stale rows.  (Since round 4 that failure is the reference's
+    own: valuefunc's linter_extrap refuses a table with one row beside the a0 row, egdst_lib.c:183 -- error 10 at it=26; before,
+    oracle and device both went on with the one-row table and stopped in the same period with error 15.)"""
     r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu_draws.py'), '67'],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -146,7 +152,7 @@ def test_one_row_tables_read_zeros_past_their_end_in_pingpong_mode():
     assert len(lines) == 2, r.stdout
     for ln in lines:
         st, where, ev, ref_rc = eval(ln.split(' ', 3)[3])
-        assert st == 15 and where == (26, 0) and ref_rc != 0, ln
+        assert st == 10 and where == (26, 0) and ref_rc != 0, ln
 
 
 def test_plain_sequential_walk_build_agrees():
