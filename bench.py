@@ -469,9 +469,12 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     tot = np.zeros(4, dtype=np.int64)
+    step_ms = []
     for s in range(args.warmup, nsteps_all):
         if solver:
+            ts_ = time.perf_counter()
             tot += np.array(run_step(s), dtype=np.int64)
+            step_ms.append((time.perf_counter() - ts_) * 1e3)   # (every step ends with a host sync: status and counts are read back)
     sync_all()
     dt = time.perf_counter() - t0
 
@@ -544,6 +547,7 @@ def main():
                 'parallelism': 'draws sharded over %d rank(s), no data-path collective, one RCCL all-reduce of the objective' % world},
             'evals_executed_per_step': ev_exec_all / args.steps, 'evals_reference_per_step': ev_ref_all / args.steps,
             'failed_draws_per_step': nfail_all / args.steps, 'draws_per_step': ndone_all / args.steps,
+            'step_ms_rank0': [round(t, 2) for t in step_ms],
             'capacity_retries': main_extra['capacity_retries'], 'schedule': main_extra['schedule'],
             'objective_mean': float(red[0].item() / max(red[1].item(), 1.0)),
             'kernel_ms_last_solve_summed_over_concurrent_streams': {n: float(v) for n, v in zip(CLASS_NAMES, kms)},

@@ -470,6 +470,9 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
     }
     double fp_last = NAN, fp_M = NAN, kp_M = 0, kp_C = 0, kp_V = 0;  // previous visit of the resend branch; the point kept last
     int fp_ncalls = -2, fp_ngen = -1, fp_np = 0, fp_nev = 0;
+    // the visits before that one (cycles of the resend, below): [0] two visits ago, [1] three, [2] four
+    double cy_last[3] = {NAN, NAN, NAN}, cy_M[3] = {NAN, NAN, NAN};
+    int cy_ncalls[3] = {-9, -9, -9}, cy_ngen[3] = {-1, -1, -1}, cy_np[3] = {0, 0, 0}, cy_nev[3] = {0, 0, 0};
     int last_cnt = 0;  // evaluations of the most recent expectation
     int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
@@ -568,6 +571,34 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                         break;
                     }
                 }
+                // A CYCLE of the resend: the re-sent guess signals c1<=0 again at ANOTHER shock node, the guess prepared for that node
+                // signals it at the first one again, and so on -- the same (guess, M) as two, three or four visits ago with nothing
+                // but resend visits in between and no point kept.  The generator's state at a visit is a function of (guess, M) and of
+                // constants of the stream, so the visits repeat with that period up to the runaway guard (:963-978); seen on C2 with
+                // a0 = -5 (one draw in ~10 000: 10 000 sequential calls of 9 us, a whole batch waiting 90 ms for one wave).  The
+                // remaining calls are accounted for: evaluations credited phase by phase, nothing kept.
+                for (int q = 0; q < 3; q++) {
+                    const int per = q + 2;  // the period this entry would prove
+                    if (!(last == cy_last[q] && M == cy_M[q] && ncalls == cy_ncalls[q] + per && ngenerated == cy_ngen[q] && np == cy_np[q])) continue;
+                    const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still run before the guard ends the stream
+                    if (k <= 0) break;
+                    // evaluations of the calls after the visits of one period, oldest first: entry q, ..., entry 0, the previous visit, now
+                    int at[5];
+                    for (int j = 0; j <= q; j++) at[j] = cy_nev[q - j];
+                    at[q + 1] = fp_nev, at[q + 2] = nev;
+                    long long add = (long long)(k / per) * (long long)(nev - cy_nev[q]);
+                    for (int j = 0; j < k % per; j++) add += at[j + 1] - at[j];
+                    nev += (int)add;
+                    if (lead && add > 0) atomicAdd(&b.credited[draw], (unsigned long long)add);
+                    skipped += k + 1;
+                    ncalls = b.g.ngridmax;
+                    break;
+                }
+                if (ncalls >= b.g.ngridmax) break;
+                for (int q = 2; q > 0; q--)
+                    cy_last[q] = cy_last[q - 1], cy_M[q] = cy_M[q - 1], cy_ncalls[q] = cy_ncalls[q - 1], cy_ngen[q] = cy_ngen[q - 1], cy_np[q] = cy_np[q - 1],
+                    cy_nev[q] = cy_nev[q - 1];
+                cy_last[0] = fp_last, cy_M[0] = fp_M, cy_ncalls[0] = fp_ncalls, cy_ngen[0] = fp_ngen, cy_np[0] = fp_np, cy_nev[0] = fp_nev;
                 fp_last = last, fp_M = M, fp_ncalls = ncalls, fp_ngen = ngenerated, fp_np = np, fp_nev = nev;
                 ncalls += 1;
                 keep = 1;
@@ -975,14 +1006,15 @@ static __device__ __forceinline__ int eg_second_bracket(double x, int i, double 
 // instructions, 2981 scalar).  A NaN x fails every comparison of the reference and its bisection runs up to row n-3: the same here.
 template <class P> static __device__ __forceinline__ int eg_last_le(double x, P g, int nrows)  // last row of [0, nrows) with g <= x, or 0
 {
-    int base = 0;
+    P p = g;  // (the position as a pointer: one add per step, no index-to-address shift)
     for (int len = nrows; len > 1;) {
         const int half = len >> 1;
-        const double gj = g[base + half];
-        base = (gj <= x) ? base + half : base;
+        P q = p + half;
+        const double gj = *q;
+        p = (gj <= x) ? q : p;
         len -= half;
     }
-    return base;
+    return (int)(p - g);
 }
 template <class P> static __device__ __forceinline__ int eg_bracket_sorted(double x, P g, int n)
 {

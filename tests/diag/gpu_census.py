@@ -1,6 +1,6 @@
 """Diagnostic: what the slow paths of a C2 batch are given to do (-DEGDST_CENSUS build: k_envelope's cells and jobs with the reason
 the throughput path left them, k_fixup's streams, slow k_probe waves).
-   python tests/diag/gpu_census.py [a0=-5] [ndraw=4096] [flags: batch|default]"""
+   python tests/diag/gpu_census.py [a0=-5] [ndraw=4096] [flags: batch|default] [perturbation seed]"""
 import ctypes as C
 import os, sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
@@ -10,9 +10,12 @@ from egdst_amd import build, examples, runtime, workloads
 a0 = float(sys.argv[1]) if len(sys.argv) > 1 else -5.0
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 var = sys.argv[3] if len(sys.argv) > 3 else 'batch'
+pert = int(sys.argv[4]) if len(sys.argv) > 4 else -1   # >= 0: the draws moved by 0.5 % with this seed (gpu_groups_sweep.py, bench.py)
 m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
 _, gen = workloads.c2(a0=0)
 P = gen(nd)
+if pert >= 0:
+    P = P * (1 + 0.005 * (2 * np.random.default_rng(pert).random(P.shape) - 1))
 flags = (workloads.BATCH_BUILD_FLAGS['C2'] if var == 'batch' else []) + ['-DEGDST_CENSUS']
 lib = build.build_model(m, extra_flags=flags)
 L = lib.lib

@@ -775,3 +775,34 @@ def test_walk_variants_agree_on_a_batch(monkeypatch):
         assert np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2], equal_nan=True), k
         for x, y in zip(a[3], b_[3]):
             assert np.array_equal(x, y), k
+
+
+def test_cycle_of_the_zero_consumption_resend_is_accounted_for_not_executed():
+    """C2 on the surveyed credit limit: a draw whose guess stream (it=14, worker) enters a CYCLE of the resend -- the re-sent guess
+    signals c1<=0 at another shock node, the guess prepared for that node signals it at the first one again -- which the reference
+    follows for ngridmax calls until its runaway guard (egdst_solver.c:963-978).  The device recognises the period (two to four
+    visits) and credits the remaining calls; status, error text and the solved cells must be the oracle's, which executes them."""
+    from oracle_harness import Oracle
+    from make_golden_big import cell_sums
+    m, gen = workloads.c2()
+    P = gen(4096)
+    P = P * (1 + 0.005 * (2 * np.random.default_rng(3).random(P.shape) - 1))
+    idx = [2833, 0, 1, 2]
+    lib = build.build_model(m)
+    s = runtime.Solver(lib, m.descriptor(), ndraw=len(idx), keep_history=True)
+    s.set_params(P[idx])
+    s.solve(raise_on_error=False)
+    st = s.status()[0]
+    assert s.evals_credited()[0] > 50000 and s.work()[0] < 1000      # ~10 000 calls of ~10 evaluations credited, none executed
+    orc = Oracle(m)
+    for k, d in enumerate(idx):
+        r = orc.solve(P[d])
+        assert (r.rc == 0) == (st[k] == 0), (d, st[k], r.err)
+        if r.rc:
+            assert lib.lib.egdst_strerror(int(st[k])).decode().strip() == r.err.strip(), d
+        else:
+            assert s.evals()[1][k] == r.nevals, d
+        ln, th = s.dims(k)
+        assert np.array_equal(ln, r.len) and np.array_equal(th, r.thlen), d
+        assert np.array_equal(s.checksums(k), cell_sums(r)), d
+    s.close()
