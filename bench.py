@@ -276,9 +276,14 @@ def serial_profile(solver):
     return ms, launches
 
 
-def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None, chunk=None, sync=None, counters_as=None):
+def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None, chunk=None, sync=None, counters_as=None, shard=None):
     """One warm-up and one timed step of `ndraw` draws of a workload through one handle of `chunk` draws (default: all of
-    them): the per-GPU share of a stress configuration.  Returns the leg's record."""
+    them): the per-GPU share of a stress configuration.  Returns the leg's record.
+
+    shard = (world, rank, all_gather_object): `params` holds the draws of the WHOLE job and this rank solves its shard of them --
+    the interleave d mod world in the warm-up step, whose per-draw counters (evaluations, re-basing calls) are then exchanged over the
+    host-side group and give the cost-balanced shards of the timed step (parallel.shard_indices: as an estimation loop would
+    re-balance from its previous iteration)."""
     import torch
     from egdst_amd import build, parallel, runtime, workloads
     if model is None:
@@ -289,10 +294,29 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
     desc = model.descriptor()
     if params is None:
         params = drawgen(ndraw) if drawgen else np.tile(model.param_vector(), (ndraw, 1))
+    params_all, my_idx, balance = params, None, None
+    if shard is not None:
+        world_, rank_, gather_ = shard
+        my_idx = parallel.shard_indices(len(params_all), world_, rank_)
+        params = params_all[my_idx]
     plan = parallel.plan_chunks(ndraw, chunk)
     solver = runtime.Solver(lib, desc, ndraw=chunk, keep_history=False)
     rec = {}
     for timed in (False, True):
+        if timed and shard is not None:
+            # the warm-up's counters of every draw of the job -> cost-balanced shards for the timed step
+            mine = np.stack([my_idx.astype(np.float64), parallel.draw_cost(cost_ev, cost_wk)]) if len(my_idx) else np.zeros((2, 0))
+            parts = gather_(mine)
+            cost = np.zeros(len(params_all))
+            for part in parts:
+                cost[part[0].astype(np.int64)] = part[1]
+            my_idx = parallel.shard_indices(len(params_all), world_, rank_, cost)
+            params = params_all[my_idx]
+            ndraw = len(my_idx)
+            plan = parallel.plan_chunks(ndraw, chunk)
+            balance = {'max_over_mean_shard_cost_interleaved': parallel.shard_balance(cost, world_, by_cost=False),
+                       'max_over_mean_shard_cost_balanced': parallel.shard_balance(cost, world_, by_cost=True)}
+        cost_ev, cost_wk = np.zeros(ndraw), np.zeros(ndraw)
         if sync:
             sync()
         torch.cuda.synchronize()
@@ -310,6 +334,8 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
             ev_ref += int(per[:valid].sum())
             ev_exec += int((per[:valid] - cred[:valid])[ok].sum())
             nfail += int((~ok).sum())
+            if shard is not None and not timed:
+                cost_ev[c0:c0 + valid], cost_wk[c0:c0 + valid] = per[:valid], solver.work()[:valid]
         if sync:
             sync()
         dt = time.perf_counter() - t0
@@ -329,6 +355,8 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
     out['roofline'] = roofline_record('%s_ndraw%d' % (counters_as or workload, chunk), kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value,
                                       rec['dt'] * 1e3 / max(len(plan), 1), chunk * nst * nt, int(tps[:, 1].sum()) if lib.info.nd > 1 else chunk * nst * nt,
                                       int(regen.sum()), serial_ms=serial_ms, serial_launch=serial_launch)
+    if balance:
+        out['shard_balance'] = balance
     out['_raw'] = rec
     return out
 
@@ -516,9 +544,15 @@ def main():
         torch.cuda.empty_cache()
         strong = {}
         for wl, total, ch in ((('C5', 32, 8), ('C4', 8, 4)) if args.rehearse_legs else (('C5', 1024, 128), ('C4', 256, 32))):
-            lo2, hi2 = parallel.shard_bounds(total, world, rank)
+            lo2, hi2 = parallel.shard_bounds(total, world, rank)   # (the shard SIZES; which draws: parallel.shard_indices, see timed_leg)
             m2, gen2 = workloads.WORKLOADS[wl]()
-            rec = timed_leg(wl, hi2 - lo2, model=m2, params=gen2(total)[lo2:hi2], chunk=ch, sync=sync_all) if hi2 > lo2 else None
+
+            def gather_obj(x):
+                outl = [None] * world
+                dist.all_gather_object(outl, x)   # (host side, gloo: between the warm-up and the timed step)
+                return outl
+            rec = timed_leg(wl, len(parallel.shard_indices(total, world, rank)), model=m2, params=gen2(total), chunk=ch, sync=sync_all,
+                            shard=(world, rank, gather_obj)) if total >= world else None
             raw = rec['_raw'] if rec else {'dt': 0.0, 'ev_ref': 0, 'ev_exec': 0, 'nfail': 0}
             t2 = torch.tensor([raw['dt']], dtype=torch.float64)
             c2 = torch.tensor([float(raw['ev_ref']), float(raw['ev_exec']), float(raw['nfail'])], dtype=torch.float64)

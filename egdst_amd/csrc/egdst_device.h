@@ -54,8 +54,8 @@ struct Batch {
     int *defer;             // [ndraw*MS_NST] cell left for the large-LDS pass of k_envelope
     int *thw, *thhw;        // rows / thresholds of the cell that may be non-zero (>= tlen, tthlen)
     // candidates of the EGM step: index (((draw*MS_NST+ist)*MS_ND+id)*Cp + n); n=0 is the probe's point
-    double *cM, *cC, *cV, *cR;  // M, C, V, and the M returned to the guess generator
-    int *cSt, *cCnt;            // status (0 normal, 1 c1<=0, 2 evf=-inf), evaluations done for the point
+    double *cM, *cC, *cV;       // M (for a point that is not normal: what it reports back to the guess generator), C, V
+    int *cSt;                   // status and evaluations done for the point, packed (egdst_kernels.hip: eg_sc_pack)
     struct ProbeOut *probe;     // [(draw*MS_NST+ist)*MS_ND+id]
     // envelope workspaces per (draw,ist): W = (MS_ND+1)*Cp entries
     double *pM, *pC, *pV;  int *pF;    // per-choice lists, consecutive (the reference's mgridvecs)
@@ -217,6 +217,36 @@ template <class P> static __device__ __forceinline__ int eg_bracket(double x, P 
 static __device__ __forceinline__ double eg_lerp(double x, double g0, double g1, double f0, double f1)
 {
     return f1 * (x - g0) / (g1 - g0) + f0 * (g1 - x) / (g1 - g0);
+}
+
+// The same expression for the grid kernels, which are bound by the instructions they issue: its two divisions have ONE divisor.
+// hipcc expands an fp64 division into v_div_scale x2, v_rcp, two Newton-Raphson steps on the reciprocal (four fma), a product, a
+// residual, v_div_fmas and v_div_fixup -- thirteen instructions, correctly rounded; the scale and fix-up steps are the identity
+// unless an operand is zero, infinite or NaN, the residual would underflow (|numerator| < 2^-969) or the quotient or the reciprocal
+// leave the normal range.  For a divisor of at least 2^-300 (rows of an M column are at most a few thousand apart and, where they
+// differ at all, at least an ulp of an O(1) number apart) the refined reciprocal is computed ONCE here and each quotient is the
+// product, the residual and the final fma of that very sequence: the same operations on the same operands, so the same bits
+// (checked against the oracle's IEEE divisions by every parity test: ~10^10 quotients per run; a numerator is f * (x - g) with f a
+// consumption or a finite value and x - g exact zero or at least an ulp of O(1): never a nonzero number below 2^-969).  A smaller,
+// zero, negative or NaN divisor and any result that is not finite take the plain expression.  (A zero numerator gives +0 where the
+// division gives the numerator's sign: the sum of the two terms, the test c1 <= 0 and the sums the value enters do not see it.)
+#ifndef EG_LERP_SHARED
+#define EG_LERP_SHARED 1
+#endif
+static __device__ __forceinline__ double eg_lerp_fast(double x, double g0, double g1, double f0, double f1)
+{
+#if defined(EGDST_EMU) || !EG_LERP_SHARED
+    return eg_lerp(x, g0, g1, f0, f1);
+#else
+    const double d = g1 - g0, n1 = f1 * (x - g0), n0 = f0 * (g1 - x);
+    double r = __builtin_amdgcn_rcp(d);  // (computed whatever d is: nothing traps, and the test below throws a bad one away)
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    const double q1 = n1 * r, q0 = n0 * r;
+    double res = __builtin_fma(__builtin_fma(-d, q1, n1), r, q1) + __builtin_fma(__builtin_fma(-d, q0, n0), r, q0);
+    if (__builtin_expect(!(d >= 0x1p-300) || !(fabs(res) <= 0x1p1023), 0)) res = n1 / d + n0 / d;
+    return res;
+#endif
 }
 
 // One next-period table (state ist1 of period it+1), row 0 = (a0, 0, evf(a0)).

@@ -93,6 +93,16 @@ static __device__ __forceinline__ size_t eg_cand(BatchRef b, int draw, int ist, 
     return (((size_t)draw * MS_NST + ist) * MS_ND + id) * (size_t)b.g.Cp;
 }
 
+// A candidate of the grid stage is three doubles and one word: cM holds M -- or, when the point's status is not 0 (cM would be
+// NaN and is never kept), the value the evaluation REPORTS BACK to the guess generator (egdst_solver.c:595-599,632: a0-1 for
+// c1<=0, the cash at the break otherwise), which for a normal point is M itself; so the stop rule (:1100) reads cM whatever the
+// status.  cSt packs the status (low 16 bits, signed: 0 normal, 1 c1<=0, 2 evf=-inf, < 0 a hard error code) and the evaluations
+// done for the point (high 16 bits).  Until round 3 these were four arrays (cM, cR, cSt, cCnt: 24 B per point, 12 of them
+// redundant); round 4 writes and reads 28 B per candidate instead of 40.
+static __device__ __forceinline__ int eg_sc_pack(int status, int cnt) { return (int)(((unsigned)cnt << 16) | ((unsigned)status & 0xffffu)); }
+static __device__ __forceinline__ int eg_sc_status(int w) { return (int)(short)(w & 0xffff); }
+static __device__ __forceinline__ int eg_sc_count(int w) { return (int)((unsigned)w >> 16); }
+
 #ifdef EGDST_CENSUS
 // Diagnostic build (tests/diag/gpu_census.py): a log of what the slow paths of a batch were given to do -- 8 ints per record:
 // kind, draw, it, a, b, c, d, ticks of 10 ns.  kinds: 1 a sort + walk job of k_envelope (a job, b points, c functions | path << 16,
@@ -470,9 +480,14 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
     }
     double fp_last = NAN, fp_M = NAN, kp_M = 0, kp_C = 0, kp_V = 0;  // previous visit of the resend branch; the point kept last
     int fp_ncalls = -2, fp_ngen = -1, fp_np = 0, fp_nev = 0;
-    // the visits before that one (cycles of the resend, below): [0] two visits ago, [1] three, [2] four
-    double cy_last[3] = {NAN, NAN, NAN}, cy_M[3] = {NAN, NAN, NAN};
-    int cy_ncalls[3] = {-9, -9, -9}, cy_ngen[3] = {-1, -1, -1}, cy_np[3] = {0, 0, 0}, cy_nev[3] = {0, 0, 0};
+    // the visits before that one (cycles of the resend, below): [0] two visits ago, [1] three, [2] four.  In LDS, a copy per wave
+    // (every wave carries the whole generator state; its lane 0 writes): in registers the history cost k_probe 44 VGPRs and a wave
+    // per SIMD (168 -> 212)
+    __shared__ double cy_d[NW][3][2];  // guess, returned M
+    __shared__ int cy_i[NW][3][4];     // ncalls, ngenerated, np, nev at the visit
+    if (lane == 0)
+        for (int q = 0; q < 3; q++) cy_i[wave][q][0] = -9;
+    EG_WSYNC();
     int last_cnt = 0;  // evaluations of the most recent expectation
     int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
@@ -579,26 +594,32 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                 // remaining calls are accounted for: evaluations credited phase by phase, nothing kept.
                 for (int q = 0; q < 3; q++) {
                     const int per = q + 2;  // the period this entry would prove
-                    if (!(last == cy_last[q] && M == cy_M[q] && ncalls == cy_ncalls[q] + per && ngenerated == cy_ngen[q] && np == cy_np[q])) continue;
+                    if (!(last == cy_d[wave][q][0] && M == cy_d[wave][q][1] && ncalls == cy_i[wave][q][0] + per && ngenerated == cy_i[wave][q][1] &&
+                          np == cy_i[wave][q][2]))
+                        continue;
                     const int k = b.g.ngridmax - 1 - ncalls;  // calls that would still run before the guard ends the stream
                     if (k <= 0) break;
-                    // evaluations of the calls after the visits of one period, oldest first: entry q, ..., entry 0, the previous visit, now
-                    int at[5];
-                    for (int j = 0; j <= q; j++) at[j] = cy_nev[q - j];
-                    at[q + 1] = fp_nev, at[q + 2] = nev;
-                    long long add = (long long)(k / per) * (long long)(nev - cy_nev[q]);
-                    for (int j = 0; j < k % per; j++) add += at[j + 1] - at[j];
-                    nev += (int)add;
+                    // evaluations of the remaining calls: whole periods (the count now minus the count `per` visits ago) and the first
+                    // k mod per calls of one more (the count at the visit that many after the old one, minus the old one's)
+                    const int m = k % per, at0 = cy_i[wave][q][3], atm = (m <= q) ? cy_i[wave][q - min(m, q)][3] : fp_nev;
+                    const int add = (k / per) * (nev - at0) + (atm - at0);
+                    nev += add;
                     if (lead && add > 0) atomicAdd(&b.credited[draw], (unsigned long long)add);
                     skipped += k + 1;
                     ncalls = b.g.ngridmax;
                     break;
                 }
                 if (ncalls >= b.g.ngridmax) break;
-                for (int q = 2; q > 0; q--)
-                    cy_last[q] = cy_last[q - 1], cy_M[q] = cy_M[q - 1], cy_ncalls[q] = cy_ncalls[q - 1], cy_ngen[q] = cy_ngen[q - 1], cy_np[q] = cy_np[q - 1],
-                    cy_nev[q] = cy_nev[q - 1];
-                cy_last[0] = fp_last, cy_M[0] = fp_M, cy_ncalls[0] = fp_ncalls, cy_ngen[0] = fp_ngen, cy_np[0] = fp_np, cy_nev[0] = fp_nev;
+                EG_WSYNC();  // (every lane has read the history)
+                if (lane == 0) {
+                    for (int q = 2; q > 0; q--) {
+                        cy_d[wave][q][0] = cy_d[wave][q - 1][0], cy_d[wave][q][1] = cy_d[wave][q - 1][1];
+                        for (int j = 0; j < 4; j++) cy_i[wave][q][j] = cy_i[wave][q - 1][j];
+                    }
+                    cy_d[wave][0][0] = fp_last, cy_d[wave][0][1] = fp_M;
+                    cy_i[wave][0][0] = fp_ncalls, cy_i[wave][0][1] = fp_ngen, cy_i[wave][0][2] = fp_np, cy_i[wave][0][3] = fp_nev;
+                }
+                EG_WSYNC();
                 fp_last = last, fp_M = M, fp_ncalls = ncalls, fp_ngen = ngenerated, fp_np = np, fp_nev = nev;
                 ncalls += 1;
                 keep = 1;
@@ -876,7 +897,15 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_probe(const Batch *bp_, int it)
+#ifndef PROBE_WAVES
+#define PROBE_WAVES 3  // waves per SIMD k_probe is compiled for (at most 168 VGPRs): a latency-bound kernel of one-wave workgroups lives on
+#endif                 // how many of them share a SIMD (round 4: the cycle history of the resend took it to 181 VGPRs and 7.1 -> 9.4 ms per C2 solve)
+#ifdef EGDST_EMU
+#define PROBE_ATTR
+#else
+#define PROBE_ATTR __attribute__((amdgpu_waves_per_eu(PROBE_WAVES, PROBE_WAVES)))
+#endif
+__global__ void __launch_bounds__(WAVE) PROBE_ATTR k_probe(const Batch *bp_, int it)
 {
     BatchRef b = EG_BATCH_REF(bp_);
     const int combo = blockIdx.x;
@@ -907,8 +936,8 @@ __global__ void __launch_bounds__(WAVE) k_fixup_scan(const Batch *bp_, int it, i
         const int n = base + lane;
         int stop = 0, neg = 0;
         if (n <= navail) {
-            stop = !(b.cR[co + n] < b.g.mmax);
-            neg = (b.cSt[co + n] == 1);
+            stop = !(b.cM[co + n] < b.g.mmax);
+            neg = (eg_sc_status(b.cSt[co + n]) == 1);
         }
         const unsigned long long ms = __ballot(stop), mn = __ballot(neg);
         if (mn) {
@@ -963,10 +992,8 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(const Batch *bp_, int it)
     const LaneEval r = eg_lane_eval(b, &E, &cur, slot1, draw, A);
     const size_t o = eg_cand(b, draw, ist, id) + n;
     if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
-    b.cCnt[o] = r.cnt;
-    b.cSt[o] = r.status;
-    b.cR[o] = r.R;
-    b.cM[o] = r.M;
+    b.cSt[o] = eg_sc_pack(r.status, r.cnt);
+    b.cM[o] = r.R;  // (== r.M for a normal point, see eg_sc_pack)
     if (r.status == 0) {
         b.cC[o] = r.C;
         b.cV[o] = r.V;
@@ -1066,7 +1093,7 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
     // rows i and i+1 of C and of V in ONE round of global reads: away from the table's ends valuefunc's bracket is the same
     // pair of rows (j+1 == i below), and a lane that waits twice per evaluation waits half as often
     const double Ci = t.C[i], Ci1 = t.C[i + 1], Vi = t.V[i], Vi1 = t.V[i + 1];
-    double c1 = eg_lerp(x, M[i], M[i + 1], Ci, Ci1);
+    double c1 = eg_lerp_fast(x, M[i], M[i + 1], Ci, Ci1);
     if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
     *t_rhs = 0;
     *t_evf = 0;
@@ -1093,7 +1120,7 @@ static __device__ __forceinline__ double eg_term_lds(const ms_env *E, const eg_l
                 const double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
                 val = f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
             } else
-                val = eg_lerp(x, g0, g1, f0, f1);
+                val = eg_lerp_fast(x, g0, g1, f0, f1);
         }
     }
     *t_evf = pr1 * val;
@@ -1137,7 +1164,7 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
     const double mlast = edge[3], mfirst = edge[0];
     // (rows i and i+1 of M, C and V in one round of global reads, see eg_term_lds)
     const double Mi = t.M[i], Mi1 = t.M[i + 1], Ci = t.C[i], Ci1 = t.C[i + 1], Vi = t.V[i], Vi1 = t.V[i + 1];
-    double c1 = eg_lerp(x, Mi, Mi1, Ci, Ci1);
+    double c1 = eg_lerp_fast(x, Mi, Mi1, Ci, Ci1);
     if (x > mlast) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
     *t_rhs = 0;
     *t_evf = 0;
@@ -1165,7 +1192,7 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
                 const double tx = ms_tr(E, nxt, x - a0), t0 = ms_tr(E, nxt, g0 - a0), t1 = ms_tr(E, nxt, g1 - a0);
                 val = f1 * (tx - t0) / (t1 - t0) + f0 * (t1 - tx) / (t1 - t0);
             } else
-                val = eg_lerp(x, g0, g1, f0, f1);
+                val = eg_lerp_fast(x, g0, g1, f0, f1);
         }
     }
     *t_evf = pr1 * val;
@@ -1444,10 +1471,8 @@ template <int PPL, bool CV = false> static __device__ __forceinline__ void eg_gr
     for (int j = 0; j < PPL; j++) {
         if (j >= np) continue;
         if (r[j].status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;  // (rare; k_fixup_scan looks closer)
-        b.cCnt[o + j] = r[j].cnt;
-        b.cSt[o + j] = r[j].status;
-        b.cR[o + j] = r[j].R;
-        b.cM[o + j] = r[j].M;
+        b.cSt[o + j] = eg_sc_pack(r[j].status, r[j].cnt);
+        b.cM[o + j] = r[j].R;  // (== r[j].M for a normal point, see eg_sc_pack)
         if (r[j].status == 0) {
             b.cC[o + j] = r[j].C;
             b.cV[o + j] = r[j].V;
@@ -1468,6 +1493,7 @@ __global__ void __launch_bounds__(GRID_BS, GRID_MINW) k_grid_lds_cv(const Batch 
 {
     eg_grid_lds_body<1, true>(EG_BATCH_REF(bp_), it, lrows);
 }
+#ifdef EGDST_WITH_GRID_PPL  // diagnostic builds only (tests/diag/gpu_grid_ppl.py): measured not faster in round 3
 #ifndef GRID_N_MINW
 #define GRID_N_MINW 1  // (the lane's points side by side want registers: 133 VGPRs by default, three waves per SIMD)
 #endif
@@ -1475,6 +1501,7 @@ __global__ void __launch_bounds__(GRID_BS, GRID_N_MINW) k_grid_lds_n(const Batch
 {
     eg_grid_lds_body<GRID_PPL>(EG_BATCH_REF(bp_), it, lrows);
 }
+#endif
 
 // k_grid for small batches: 16 lanes per grid point, a lane per shock node (eg_wave_expectation with groups of 16),
 // so that a solve that leaves the GPU mostly idle does not spend 20 serial shock terms per point: same arithmetic and
@@ -1526,10 +1553,8 @@ __global__ void __launch_bounds__(EG_GRIDW_BS) k_grid_wide(const Batch *bp_, int
     }
     const size_t o = eg_cand(b, draw, ist, id) + n;
     if (r.status == 1) b.negflag[((size_t)draw * MS_NST + ist) * MS_ND + id] = 1;
-    b.cCnt[o] = r.cnt;
-    b.cSt[o] = r.status;
-    b.cR[o] = r.R;
-    b.cM[o] = r.M;
+    b.cSt[o] = eg_sc_pack(r.status, r.cnt);
+    b.cM[o] = r.R;  // (== r.M for a normal point, see eg_sc_pack)
     if (r.status == 0) {
         b.cC[o] = r.C;
         b.cV[o] = r.V;
@@ -2929,7 +2954,7 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
                 // first requested point whose returned M stops the stream (:1100): the point itself is kept
                 int first = navail + 1;
                 for (int n = 1 + tid; n <= navail; n += ENV_BS)  // (no early exit: the loads of a thread go out together)
-                    if (!(b.cR[co + n] < mmax)) first = min(first, n);
+                    if (!(b.cM[co + n] < mmax)) first = min(first, n);
                 first = blk_min(first, sh);
                 nreq = min(first, navail);
                 fusedstats = 1;
@@ -2957,10 +2982,10 @@ static __device__ __forceinline__ void eg_envelope_cell(BatchRef b, int it, int 
                             else if (n == 0)
                                 keep[k] = P.np;
                             else {
-                                const int st = b.cSt[co + n];
+                                const int sc = b.cSt[co + n], st = eg_sc_status(sc);
                                 if (st < 0) hard = max(hard, -st);
                                 n12 |= (st == 1) | ((st == 2) << 1);
-                                ev += b.cCnt[co + n];
+                                ev += eg_sc_count(sc);
                                 keep[k] = (st == 0 && isfinite(vM[k]));
                             }
                         }
@@ -3375,7 +3400,7 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
         const int navail = P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0;
         int first = navail + 1;
         for (int n = 1 + tid; n <= navail; n += TP_BS)
-            if (!(b.cR[co + n] < mmax)) first = min(first, n);
+            if (!(b.cM[co + n] < mmax)) first = min(first, n);
         first = blk_min(first, sh);
         nreq = min(first, navail);
         fusedstats = 1;
@@ -3400,10 +3425,10 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
                     else if (n == 0)
                         keep[k] = P.np;
                     else {
-                        const int st = b.cSt[co + n];
+                        const int sc = b.cSt[co + n], st = eg_sc_status(sc);
                         if (st < 0) hard = max(hard, -st);
                         n12 |= (st == 1) | ((st == 2) << 1);
-                        ev += b.cCnt[co + n];
+                        ev += eg_sc_count(sc);
                         keep[k] = (st == 0 && isfinite(vM[k]));
                     }
                 }
@@ -3864,6 +3889,7 @@ __global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk_big(const 
         __syncthreads();  // (the LDS of the cell is reused by the next one)
     }
 }
+#ifdef EGDST_WITH_TP_LONG  // diagnostic builds only (tests/diag/gpu_tp_long.py): measured not faster than k_envelope's global walk in round 3
 #ifdef EGDST_EMU
 #define TP_WALKG_BS ENV_BS_EMU
 #else
@@ -3874,6 +3900,7 @@ __global__ void __launch_bounds__(TP_WALKG_BS, TP_WALK_MINW) k_tp_walk_g(const B
     __shared__ TpShared S;
     tp_walk<true>(EG_BATCH_REF(bp_), it, stage, list, cnt, 0, (int)blockIdx.x, &S, nullptr);
 }
+#endif
 
 // (Measured and not kept: the same phases FUSED into two kernels -- per (cell, choice) the list, its sort and its secondary
 //  envelope; per cell the sort of the lists and the primary envelope -- so that a launch costs the slowest chain of phases
@@ -3903,7 +3930,7 @@ static __device__ __forceinline__ bool e1_kept(BatchRef b, const ProbeOut &P, si
 {
     if (terminal) return true;
     if (n == 0) return P.np != 0;
-    return b.cSt[co + n] == 0 && isfinite(b.cM[co + n]);
+    return eg_sc_status(b.cSt[co + n]) == 0 && isfinite(b.cM[co + n]);
 }
 // candidate range [lo, hi) of workgroup blk of nb, for requested candidates 0..nreq
 static __device__ __forceinline__ void e1_range(int nreq, int blk, int nb, int *lo, int *hi)
@@ -3933,7 +3960,7 @@ __global__ void __launch_bounds__(E1_BS) k_env1_a(const Batch *bp_, int it, int 
     e1_range(navail, blockIdx.x, nb, &lo, &hi);
     int first = 0x7fffffff;
     for (int n = max(lo, 1) + (int)threadIdx.x; n < hi; n += E1_BS)
-        if (!(b.cR[co + n] < b.g.mmax)) {
+        if (!(b.cM[co + n] < b.g.mmax)) {
             first = n;
             break;
         }
@@ -3953,10 +3980,10 @@ static __device__ __forceinline__ int e1_count(BatchRef b, const ProbeOut &P, si
     double pm = 0, pv = 0;
     for (int n = a; n < z; n++) {
         if (!write && n >= 1 && !terminal) {
-            const int st = b.cSt[co + n];
+            const int sc = b.cSt[co + n], st = eg_sc_status(sc);
             if (st < 0 || st == 1) *flags |= E1_IRREGULAR;  // hard error / c1<=0 left over: k_envelope reports it
             if (st == 2) *n2 += 1;
-            *ev += (unsigned long long)b.cCnt[co + n];
+            *ev += (unsigned long long)eg_sc_count(sc);
         }
         if (!e1_kept(b, P, co, n, terminal)) continue;
         const double m = b.cM[co + n], v = b.cV[co + n];

@@ -34,7 +34,7 @@ ABI_SYMBOLS = ['egdst_get_model_info', 'egdst_strerror', 'egdst_last_error', 'eg
                'egdst_create_compact', 'egdst_geometry', 'egdst_set_groups', 'egdst_set_adaptive', 'egdst_get_schedule', 'egdst_get_work', 'egdst_get_regenerations', 'egdst_call', 'egdst_simulate_moments',
                'egdst_get_checksums', 'egdst_math_eval', 'egdst_get_evals_credited', 'egdst_simulate_batch_moments',
                'egdst_uniform', 'egdst_set_dbgout', 'egdst_get_dbgout', 'egdst_get_walk_stats',
-               'egdst_set_cell_M', 'egdst_set_cell_D', 'egdst_set_solution', 'egdst_get_tp_stats']
+               'egdst_set_cell_M', 'egdst_set_cell_D', 'egdst_set_solution', 'egdst_get_tp_stats', 'egdst_get_group_profile']
 
 
 class EgdstRuntimeError(RuntimeError):
@@ -424,6 +424,15 @@ class Solver:
         ab = C.c_longlong(0)
         self.lib.check(self.lib.lib.egdst_get_profile(self.h, _dp(ms), _ip(ln), C.byref(ab)))
         return ms, ln, int(ab.value)
+
+    def group_profile(self):
+        """(finish[g], class_ms[g, 9]) of the last solve with profiling on: ms from the first group's first kernel to the end of group
+        g's last kernel, and the group's summed HIP-event time per kernel class (egdst_get_group_profile)"""
+        fin = np.zeros(32)
+        cls = np.zeros((32, 9))
+        self.lib.lib.egdst_get_group_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        n = self.lib.lib.egdst_get_group_profile(self.h, 32, _dp(fin), _dp(cls))
+        return fin[:n], cls[:n]
 
     def debug(self, draw=0):
         out = np.zeros(16, dtype=np.int32)

@@ -215,6 +215,10 @@ int egdst_get_objective(egdst_handle *h, double *out /* host, [2*ndraw] */);
  * 24 B per row written, 16 B per threshold). */
 int egdst_set_profile(egdst_handle *h, int on);
 int egdst_get_profile(egdst_handle *h, double *ms /* [9] */, int *launches /* [9] */, long long *algbytes);
+/* The same events read per draw group (profiling on): for each of the groups of the last solve, ms from the start of the FIRST
+ * group's first kernel to the end of this group's last kernel (out_ms[g]) -- how evenly the groups finish -- and the sum of this
+ * group's bracketed kernel time per class (out_class_ms[g * 9 + k], may be NULL).  Returns the number of groups (<= max_groups). */
+int egdst_get_group_profile(egdst_handle *h, int max_groups, double *out_ms, double *out_class_ms);
 
 /* Diagnostics of a tripped internal guard (EGDST_E_INTERNAL and 27xx codes): 16 ints, meaning is internal. */
 int egdst_get_debug(egdst_handle *h, int draw, int *out16);

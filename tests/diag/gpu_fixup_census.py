@@ -3,7 +3,8 @@ import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-m, gen = workloads.c2(a0=0)
+import os
+m, gen = workloads.c2(a0=float(os.environ.get('EGDST_DIAG_A0', '0')))
 lib = build.build_model(m, extra_flags=['-DEGDST_FIXSTAT'] + sys.argv[2:])
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 P = gen(nd)

@@ -11,7 +11,7 @@ P = gen(nd) if gen else np.tile(m.param_vector(), (nd, 1))
 ref = None
 for var in variants:
     flags = [f for f in var.split('+') if f]
-    lib = build.build_model(m, extra_flags=flags)
+    lib = build.build_model(m, extra_flags=list(flags) + ['-DEGDST_WITH_GRID_PPL'])   # (k_grid_lds_n is compiled into diagnostic builds only)
     for ppl in ('0', '1'):
         os.environ['EGDST_GRID_PPL'] = ppl
         s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)

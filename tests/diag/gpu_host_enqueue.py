@@ -5,7 +5,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m, gen = workloads.c2(a0=0)
-lib = build.build_model(m, extra_flags=sys.argv[2:])
+lib = build.build_model(m, extra_flags=sys.argv[2:] + ['-DEGDST_WITH_GRAPH'])   # (the hipGraph replay is compiled into diagnostic builds only)
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
 s.set_params(gen(nd))
 s.solve(raise_on_error=False)

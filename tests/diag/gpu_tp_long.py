@@ -10,7 +10,7 @@ m, gen = workloads.WORKLOADS[wl]()
 P = gen(nd) if gen else np.tile(m.param_vector(), (nd, 1))
 kh = len(sys.argv) > 3 and sys.argv[3] == 'history'
 flags = workloads.BATCH_BUILD_FLAGS.get(wl, []) if nd >= workloads.BATCH_BUILD_MIN_DRAWS.get(wl, 1 << 30) else []
-lib = build.build_model(m, extra_flags=flags)
+lib = build.build_model(m, extra_flags=list(flags) + ['-DEGDST_WITH_TP_LONG'])   # (k_tp_walk_g is compiled into diagnostic builds only)
 ref = None
 for tp in ('0', '1'):
     os.environ['EGDST_ENV_TP'] = tp

@@ -266,18 +266,16 @@ TP_CASES = {
 
 
 @pytest.mark.parametrize('name', sorted(TP_CASES))
-@pytest.mark.parametrize('keys', ['lds_keys', 'sampled_keys', 'global_walk'])
+@pytest.mark.parametrize('keys', ['lds_keys', 'sampled_keys'])
 def test_throughput_envelope_path_bit_exact(name, keys, monkeypatch):
     """The envelope step of big batches runs as five lean kernels with one wave per walk (k_tp_prep / k_tp_sort / k_tp_walk,
     egdst_kernels.hip) and hands the cells it does not take to k_envelope.  Forced on here for single solves (EGDST_ENV_TP=1):
     tables, thresholds and evaluation counts equal the oracle's bit for bit, with the sort's M keys whole in LDS and with so
-    little LDS that it works on a sampled index of them; with the walks over global memory, as for streams too long for LDS
-    (k_tp_walk_g, EGDST_TP_LONG); and the path really does the cells (egdst_get_tp_stats)."""
+    little LDS that it works on a sampled index of them; and the path really does the cells (egdst_get_tp_stats).  (The walks over
+    global memory, k_tp_walk_g, were measured slower in round 3 and are compiled into diagnostic builds only since round 4.)"""
     monkeypatch.setenv('EGDST_ENV_TP', '1')
     if keys != 'lds_keys':
         monkeypatch.setenv('EGDST_TP_SORT_LKCAP', '96')
-    if keys == 'global_walk':
-        monkeypatch.setenv('EGDST_TP_LONG', '2')
     m = TP_CASES[name]()
     s = gpu_solve(m)
     sol = s.solution(0)
@@ -558,12 +556,13 @@ def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
 
 
 @pytest.mark.parametrize('name', ['retirement2', 'occ3_n400', 'retire8', 'C2', 'deaton_n4096', 'cake_normal'])
-def test_neighbour_hinted_bracket_search_is_the_binary_search(name, monkeypatch):
-    """k_grid_lds_n (EGDST_GRID_PPL=1): a lane evaluates four consecutive asset points side by side and starts each bracket search
-    at the neighbouring point's bracket (eg_bracket_near) -- the 'search bound from the neighbour' of SURVEY section 7.  On an
-    ordered column the bracket is unique however it is found: tables, thresholds and evaluation counts equal the oracle's bit
-    for bit, with whole columns in LDS and with the sampled index (the near search then steps through the global column)."""
-    monkeypatch.setenv('EGDST_GRID_PPL', '1')
+def test_branch_free_bracket_search_is_the_binary_search(name, monkeypatch):
+    """k_grid_lds on single draws (EGDST_GRID_WIDE=0): the bracket of every evaluation comes from the branch-free bisection with a
+    uniform step count (eg_bracket_sorted, eg_bracket_sampled: round 4), which on an ordered column must land where the reference's
+    bxsearch_common lands (egdst_lib.c:136-166) -- and the two divisions of every interpolation share one refined reciprocal
+    (eg_lerp_fast).  Tables, thresholds and evaluation counts equal the oracle's bit for bit, with whole columns in LDS and with
+    the sampled index (the search is then finished in the window of the global column).  (The neighbour-hinted search this test
+    covered until round 3, k_grid_lds_n, was measured slower and is compiled into diagnostic builds only.)"""
     monkeypatch.setenv('EGDST_GRID_WIDE', '0')
     m = {'retirement2': lambda: examples.retirement2(), 'occ3_n400': SCALED['occ3_n400'], 'retire8': lambda: examples.retirement8(T=12, ngridm=150, ny=5),
          'C2': SCALED['C2'], 'deaton_n4096': SCALED['deaton_n4096'], 'cake_normal': lambda: examples.cake_normal()}[name]()
@@ -650,27 +649,6 @@ def test_solver_gateway_third_output_dbgout(name):
     assert np.array_equal(out[:n][out[:n, 2] == -1, 3], th)   # the primary rows are the thresholds of the D cells
 
 
-def test_captured_graph_is_dropped_when_the_kink_log_is_switched(monkeypatch):
-    """EGDST_GRAPH=1: a solve captured while the kink log was on holds the log's device pointers in its nodes; switching the
-    log off frees them, so the captured sequence must go with them (egdst_set_dbgout) -- solve with the log, switch it off, solve
-    again (replaying the old graph would write into freed memory), switch it on again: every solve equals the oracle's and the
-    log of the last one is the oracle's."""
-    monkeypatch.setenv('EGDST_GRAPH', '1')
-    m = examples.retirement2()
-    lib = build.build_model(m)
-    s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
-    s.set_params(m.param_vector()[None])
-    ref = Oracle(m).solve(dbgout=True)
-    for on in (True, False, False, True):
-        s.set_dbgout(on)
-        assert s.solve(raise_on_error=False) == 0
-        ok, rep = compare(s.solution(0), ref, rtol=0.0, th_tol=0.0)
-        assert ok, (on, rep)
-    out, n = s.dbgout(0)
-    assert n == ref.dbgn and np.array_equal(out, ref.dbgout)
-    s.close()
-
-
 def test_class_surface_dbgout():
     m = examples.retirement2()
     m.compile()
@@ -728,6 +706,12 @@ def test_segmented_envelope_walks_are_used_and_exact(monkeypatch):
             else:
                 assert merged >= sol.nt // 2 and fallback <= merged // 4, (name, merged, fallback)
             s.close()
+
+
+# the build variants the tests of this file load besides the default libraries: (model factory, extra hipcc flags).
+# __graft_entry__.build() compiles them in-tree beforehand, so that the GPU lease never runs hipcc.
+BUILD_VARIANTS = [(lambda: TP_CASES['C2'](), ['-DEGDST_RANKCHK']), (lambda: TP_CASES['occ3_n400'](), ['-DEGDST_RANKCHK']),
+                  (lambda: workloads.c2(a0=0, ngridm=300, T=30)[0], ['-DENV_LANE_STEP=0', '-DENV_CDEFER_ON=0'])]
 
 
 @pytest.mark.parametrize('name,tp', [('C2', '0'), ('occ3_n400', '1'), ('occ3_n400', '0')])

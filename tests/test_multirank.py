@@ -88,3 +88,35 @@ def test_two_ranks_reduce_equals_single_process():
         assert p.exitcode == 0
     assert cnt == ndraw and abs(tot - ref.sum()) <= 1e-12 * abs(ref.sum())
     assert np.array_equal(allv, ref)
+
+
+def test_cost_aware_shards_partition_the_job_and_balance_the_recorded_costs():
+    """parallel.shard_indices: every draw to exactly one rank, no rank above ceil(n / world) draws, the same partition on every rank
+    (it is a pure function of its arguments), and balanced COST: on the per-draw figures recorded on an MI355X for the north_star's
+    batches (tests/golden/draw_costs_*.npz, make_draw_costs.py: evaluations and re-basing calls of the 1024 C5 and 256 C4 draws; 62
+    of the C5 draws fail and cost a sixteenth of the others) the most loaded of 8 ranks carries at most 1 % more than the mean --
+    SURVEY.md section 8(e)'s "load balance matters more than comms", the bar of the round-3 verdict being 1.1 -- and on a
+    heavy-tailed synthetic cost (a tenth of the draws ten times dearer, in a block: what contiguous shards handle worst) it stays
+    within 2 % where contiguous shards are off by more than half."""
+    rng = np.random.default_rng(5)
+    for n, w in ((1024, 8), (1000, 3), (7, 8), (256, 2)):
+        c = rng.lognormal(0, 1, n)
+        parts = [parallel.shard_indices(n, w, r, c) for r in range(w)]
+        assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+        assert max(len(p) for p in parts) <= -(-n // w)
+        assert all(np.all(np.diff(p) > 0) for p in parts if len(p) > 1)
+        assert all(np.array_equal(p, parallel.shard_indices(n, w, r, c.copy())) for r, p in enumerate(parts))
+        inter = [parallel.shard_indices(n, w, r) for r in range(w)]
+        assert sorted(np.concatenate(inter).tolist()) == list(range(n)) and all(np.array_equal(p, np.arange(r, n, w)) for r, p in enumerate(inter))
+    for wl, n in (('C5', 1024), ('C4', 256)):
+        d = np.load(os.path.join(HERE, 'golden', 'draw_costs_%s.npz' % wl))
+        c = parallel.draw_cost(d['evals'], d['work'])
+        assert len(c) == n
+        for w in (2, 4, 8):
+            assert parallel.shard_balance(c, w) <= 1.01, (wl, w, parallel.shard_balance(c, w))
+    c = np.ones(1024)
+    c[300:400] = 10.0
+    contiguous = max(c[slice(*parallel.shard_bounds(1024, 8, r))].sum() for r in range(8)) / (c.sum() / 8)
+    assert contiguous > 1.5 and parallel.shard_balance(c, 8) <= 1.02 and parallel.shard_balance(c, 8, by_cost=False) <= 1.05
+    with pytest.raises(ValueError):
+        parallel.shard_indices(8, 2, 0, np.ones(7))

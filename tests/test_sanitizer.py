@@ -104,7 +104,6 @@ def test_solution_import_serves_simulator_and_accessor(args):
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIG': '0'}),   # streams beyond the walk's LDS: left to k_envelope
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # ... done by the second tier of stage 1 (k_tp_sort_big, k_tp_walk_big)
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIGCAP': '52'}),  # ... some by the second tier, the longest by k_envelope
-    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LONG': '2', 'EGDST_TP_SORT_LKCAP': '16'}),  # walks over global memory (k_tp_walk_g)
 ])
 def test_throughput_path_of_the_envelope_step(args, env):
     """EGDST_ENV_TP=1: the envelope step as the lean kernels of big batches (k_tp_prep / k_tp_sort / k_tp_walk) with multi-lane
@@ -127,10 +126,11 @@ def test_throughput_path_of_the_envelope_step(args, env):
 
 @pytest.mark.skipif(_asan() is None, reason='libasan not found')
 @pytest.mark.parametrize('args,lds', [(['retirement2', 'T=8, ngridm=60'], ''), (['occ3', 'T=6, ngridm=30, ngridmax=100'], '24')])
-def test_several_asset_points_per_lane_with_neighbour_hinted_search(args, lds):
-    """EGDST_GRID_PPL=1: k_grid_lds_n -- a lane evaluates four consecutive asset points side by side and starts every bracket
-    search at its neighbour's bracket (eg_bracket_near); whole columns in LDS and the sampled index (EGDST_GRID_LDS)."""
-    e = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_GRID_PPL='1', EGDST_GRID_WIDE='0')
+def test_grid_kernel_with_the_branch_free_searches(args, lds):
+    """EGDST_GRID_WIDE=0: k_grid_lds on a single draw -- the branch-free bisection over whole columns in LDS (eg_bracket_sorted) and,
+    with EGDST_GRID_LDS=24, over the sampled index and the window of the global column (eg_bracket_sampled): every read in bounds,
+    results the oracle's."""
+    e = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address', EGDST_GRID_WIDE='0')
     if lds:
         e['EGDST_GRID_LDS'] = lds
     r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py')] + args, env=e, capture_output=True, text=True,
