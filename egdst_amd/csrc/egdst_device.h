@@ -214,6 +214,31 @@ template <class P> static __device__ __forceinline__ int eg_bracket(double x, P 
     return lo;
 }
 
+// eg_bracket(x, g, n, 0) on a NON-DECREASING column without NaN (the caller checked the order): bxsearch_common (egdst_lib.c:136-166)
+// returns 0 below g[1], n-2 from g[n-2] on, and between them the last row that is not above x -- on an ordered column that is
+// "the last row i in [1, n-2] with g[i] <= x, or 0", however it is found.  Here: the branch-free form of the bisection -- the
+// range [base, base+len) shrinks by len/2 per step whatever the comparison says, so every lane makes the SAME number of steps (n
+// is uniform over the workgroup) and a step is one LDS read, one compare and one select.  The reference's loop compiled to ~22
+// instructions per step, 13 of them scalar bookkeeping of the lanes that had finished (profiles/r04_*: k_grid_lds_cv 5876
+// instructions, 2981 scalar).  A NaN x fails every comparison of the reference and its bisection runs up to row n-3: the same here.
+template <class P> static __device__ __forceinline__ int eg_last_le(double x, P g, int nrows)  // last row of [0, nrows) with g <= x, or 0
+{
+    P p = g;  // (the position as a pointer: one add per step, no index-to-address shift)
+    for (int len = nrows; len > 1;) {
+        const int half = len >> 1;
+        P q = p + half;
+        const double gj = *q;
+        p = (gj <= x) ? q : p;
+        len -= half;
+    }
+    return (int)(p - g);
+}
+template <class P> static __device__ __forceinline__ int eg_bracket_sorted(double x, P g, int n)
+{
+    const int i = eg_last_le(x, g, n - 1);  // rows 0 .. n-2
+    return (x != x) ? n - 3 : i;
+}
+
 static __device__ __forceinline__ double eg_lerp(double x, double g0, double g1, double f0, double f1)
 {
     return f1 * (x - g0) / (g1 - g0) + f0 * (g1 - x) / (g1 - g0);
@@ -310,7 +335,8 @@ static __device__ __forceinline__ double eg_term(const ms_env *E, const TT &t, c
 {
     nxt->cash = ms_cashinhand(E, cur, nxt);
     const int n1 = t.len;
-    int i = eg_bracket(nxt->cash, t.M, n1, 0);
+    // (a column known to be in order, four rows or more: the branch-free bisection -- the same bracket, see eg_bracket_sorted)
+    int i = (sorted && n1 >= 4) ? eg_bracket_sorted(nxt->cash, t.M, n1) : eg_bracket(nxt->cash, t.M, n1, 0);
     double c1 = eg_lerp(nxt->cash, t.M[i], t.M[i + 1], t.C[i], t.C[i + 1]);
     if (nxt->cash > t.M[n1 - 1]) c1 = MS_MAX(c1, t.C[n1 - 1]);  // constant extrapolation, :554
     *t_rhs = 0;

@@ -820,6 +820,9 @@ template <int L> static __device__ __forceinline__ bool env_step_wave(EnvCtxT<L>
 #else
 #define EG_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0), nothing else
 #endif
+#ifndef ENV_STEP_CHAIN
+#define ENV_STEP_CHAIN 1  // consecutive irregular positions are stepped through without going back to the batches (env_walk_wave); 0: tests
+#endif
 #ifndef ENV_DUPRUN
 #define ENV_DUPRUN 1  // runs of repeated grid values at the bound are consumed 64 positions at a time (env_walk_wave); 0: one generic step each (tests)
 #endif
@@ -1401,8 +1404,12 @@ static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, in
 #else
 #define WSTAMP(acc, cnt)
 #endif
+    bool chain = false;  // the position after a generic step is irregular too (decided below): step again, the cursors are in place
     while (i < p1 && !e.err) {
         bool step_now = true;
+        if (chain) {
+            chain = false;
+        } else
         if (phase != 1) {
             if (!(e.m[i] <= e.bound)) break;
             // A run of positions that repeat the grid value of the last output row (:1290-1298).  The generic step does
@@ -1539,6 +1546,29 @@ static __device__ __forceinline__ void env_walk_wave(EnvCtxT<L> &e, int npts, in
             i++;
             if (phase == 0 && e.oj > 0) phase = 1;
             WSTAMP(w_step, w_nstep);
+            // Events come in clusters -- where a choice list folds, and along the whole stream when the pieces of a re-based guess
+            // stream lie within ulps of each other (hundreds of crossings in a row: the slowest walk of nearly every launch,
+            // profiles/r04_*).  Going back to the batches after every step costs a classification of 64 positions that commits
+            // none and a rebuild of the cursors from the position lists (a bisection per function) that the step has just left in
+            // place: a generic step keeps cur[] exactly as the reference's loop does (below the bound: count - 1, what the rebuild
+            // gives).  So: if the next position is below the bound and irregular for the new current-max function -- the batch's
+            // own test, for one position -- step again at once.
+            if (ENV_STEP_CHAIN && phase == 1 && i < p1) {
+                const double xn = e.m[i];
+                if (xn < e.bound && xn != lastg) {
+                    const int wn_ = e.cls[i], fn_ = (int)e.f[i];
+                    bool ev_;
+                    if (wn_ < 0)
+                        ev_ = true;
+                    else if (fn_ == pm)
+                        ev_ = (wn_ & 1) != 0;
+                    else if (wn_ & ENV_CLS_NOMASK)
+                        ev_ = false;  // (needs a count: the batches decide)
+                    else
+                        ev_ = ((wn_ >> (pm + 1)) & 1) != 0;
+                    chain = ev_;
+                }
+            }
         }
     }
     e.pm = pm;

@@ -40,8 +40,15 @@
 #ifndef EG_FIX_LROWS
 #define EG_FIX_LROWS 2048        // rows of the next-period table that k_fixup stages in LDS (48 KB)
 #endif
-#ifndef EG_SEQ_AFTER_RESEND
-#define EG_SEQ_AFTER_RESEND 1  // k_fixup: guesses evaluated one at a time after a c1<=0 resend (C2 x 4096: 0 or 1: 225 ms, 2-8: 228 ms)
+#ifndef FIX_LPG_SHIFT  // k_fixup: log2 of the lanes that share a guess in the small batch after a resend (0: no small batches)
+#ifdef EGDST_EMU
+#define FIX_LPG_SHIFT 0  // (the harness cannot diverge inside a wave)
+#else
+#define FIX_LPG_SHIFT 4
+#endif
+#endif
+#ifndef EG_SEQ_AFTER_RESEND  // k_fixup: guesses evaluated one at a time after a c1<=0 resend, before the next batch (with small batches: none
+#define EG_SEQ_AFTER_RESEND (FIX_LPG_SHIFT > 0 ? 0 : 1)  // -- C2 a0=-5 x 4096: 172.6 ms with one, 170.2 without; without small batches 0 or 1 were equal)
 #endif
 #ifndef FIX_BS  // threads of a k_fixup workgroup = guesses evaluated per batch of the sequential stream
 #define FIX_BS (4 * WAVE)  // one wave per SIMD: the sequential stretches run redundantly in every wave
@@ -108,9 +115,11 @@ static __device__ __forceinline__ int eg_sc_count(int w) { return (int)((unsigne
 // kind, draw, it, a, b, c, d, ticks of 10 ns.  kinds: 1 a sort + walk job of k_envelope (a job, b points, c functions | path << 16,
 // d why the throughput path left the cell), 2 a cell of k_envelope (a rows out, b thresholds, c error, d why), 3 a stream of
 // k_fixup (a choice, b points kept, c calls), 4 a k_probe wave that took long (a choice, b calls, c fast-forwarded calls),
-// 5 a walk of the throughput path that gave up (a stage, b error, c points, d rows).
+// 5 a walk of the throughput path that gave up (a stage, b error, c points, d rows), 6 every walk of the throughput path (a stage |
+// second tier << 4, b points, c functions, d workgroup).
 #define EG_CENSUS_CAP (1 << 20)
 __shared__ int cz_sh_bad;  // the sort of the current job found a list out of comp1 order (1: network, 2: counted)
+__shared__ int cz_sh_fb;   // the current walk: 0 one wave, 1 cut into segments and merged, 2 cut and fallen back to one wave, | generic steps << 8
 __device__ int g_census[EG_CENSUS_CAP * 8];
 __device__ unsigned g_census_n;
 static __device__ __forceinline__ void eg_census(int kind, int draw, int it, int a, int b_, int c, int d, unsigned long long ticks)
@@ -491,6 +500,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
     int last_cnt = 0;  // evaluations of the most recent expectation
     int skipped = 0;   // calls of the stage-0 fixed point that were accounted for without being executed
     int seq_left = 0;  // full mode: grid guesses to evaluate one at a time before batching again
+    int small = 0;     // full mode: the next batch is a small one (several lanes per guess), see the batch below
 #ifdef EGDST_FIXSTAT  // diagnostic: what a regeneration consists of (dbg ints 8..11, ticks in ints 12-13)
     int fs_batches = 0, fs_single = 0, fs_resend = 0;
     const unsigned long long fs_t0 = wall_clock64();
@@ -659,21 +669,52 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
 #ifdef EGDST_FIXSTAT
                 fs_batches++;
 #endif
-                const int gl = wave * WAVE + lane;  // position of this thread's guess in the batch
-                const int n = ngenerated + gl;      // value of `ngenerated` at this thread's call
+                // Two shapes of a batch.  The regular one: a guess per lane, its (next state, shock node) terms one after the other inside
+                // the lane (as k_grid_lds does).  Right after a resend (small != 0) the next c1<=0 is usually a few points away -- a
+                // stream re-bases five times on average, nearly always within its first dozens of points -- and a whole batch of
+                // serial evaluations is 35 us of latency for a handful of consumed guesses: then FIX_LPG lanes share a guess, a
+                // lane per shock node as in k_grid_wide (eg_wave_expectation with groups of FIX_LPG: the same terms accumulated in
+                // the same order), WAVE / FIX_LPG guesses per wave -- a quarter of the latency.  A small batch that is consumed
+                // whole without a signal hands back to the regular shape.  Only the lane (lane % lpg) == 0 of a guess votes below.
+                const int lsh = small ? FIX_LPG_SHIFT : 0, lpg = 1 << lsh, gpw = WAVE >> lsh;  // lanes per guess, guesses per wave
+                const bool rep = (lane & (lpg - 1)) == 0;
+                const int gl = wave * gpw + (lane >> lsh);  // position of this thread's guess in the batch
+                const int n = ngenerated + gl;              // value of `ngenerated` at this thread's call
                 const bool can = n < ntogenerate && (ncalls + 1 + gl) < b.g.ngridmax;
                 LaneEval r;
                 r.status = 0, r.cnt = 0, r.bist = 0, r.M = NAN, r.C = r.V = r.R = 0, r.bshock = r.bcash = 0;
                 double An = last;
                 if (can) {
                     An = eg_grid_A(&E, &cur, GL, ngenerated - 1, last, n);
+#if FIX_LPG_SHIFT > 0
+                    if (small) {
+                        double rhs_ = 0, evf_ = 0;
+                        int cnt_ = 0, st_;
+                        if (full && staged)
+                            st_ = eg_wave_expectation<TabL, (1 << FIX_LPG_SHIFT)>(b, &E, slot1, draw, &cur, An, 1, &rhs_, &evf_, &cnt_, &r.bist, &r.bshock, &r.bcash, &ltab, staged_sorted);
+                        else
+                            st_ = eg_wave_expectation<Tab, (1 << FIX_LPG_SHIFT)>(b, &E, slot1, draw, &cur, An, 1, &rhs_, &evf_, &cnt_, &r.bist, &r.bshock, &r.bcash, (const Tab *)nullptr);
+                        r.status = st_, r.cnt = cnt_;  // (what eg_lane_eval reports for the point, as in k_grid_wide)
+                        if (st_ == 0) {
+                            rhs_ *= ms_discount(&E, &cur);
+                            r.M = An + ms_utility_marginal_inverse(&E, &cur, rhs_);
+                            r.C = r.M - An;
+                            r.V = ms_utility(&E, &cur, r.C) + ms_discount(&E, &cur) * evf_;
+                            r.R = r.M;
+                        } else {
+                            r.M = NAN;
+                            r.C = r.V = 0;
+                            r.R = (st_ == 1) ? b.g.a0 - 1 : r.bcash;
+                        }
+                    } else
+#endif
                     r = (full && staged) ? eg_lane_eval<TabL>(b, &E, &cur, slot1, draw, An, &ltab, staged_sorted) : eg_lane_eval<Tab>(b, &E, &cur, slot1, draw, An);
                 }
                 {   // phase 1: what every wave found, in batch order
-                    const unsigned long long canm = __ballot(can);
-                    const unsigned long long hardm = __ballot(can && r.status < 0);
-                    const unsigned long long negm = __ballot(can && r.status == 1);
-                    const unsigned long long stopm = __ballot(can && r.status != 1 && !(r.R < mmax));
+                    const unsigned long long canm = __ballot(can && rep);
+                    const unsigned long long hardm = __ballot(can && rep && r.status < 0);
+                    const unsigned long long negm = __ballot(can && rep && r.status == 1);
+                    const unsigned long long stopm = __ballot(can && rep && r.status != 1 && !(r.R < mmax));
                     const int hst = __shfl(r.status, hardm ? __ffsll((long long)hardm) - 1 : 0);
                     if (lane == 0) {
                         sx_can[wave] = canm;
@@ -687,10 +728,10 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                 int ncan = 0, fneg = -1, fstop = -1, fhard = -1, hcode = 0;
                 for (int w = 0; w < NW; w++) {  // threads [0, ncan) of the batch hold requested-if-reached guesses
                     ncan += __popcll(sx_can[w]);
-                    if (fneg < 0 && sx_neg[w]) fneg = w * WAVE + __ffsll((long long)sx_neg[w]) - 1;
-                    if (fstop < 0 && sx_stop[w]) fstop = w * WAVE + __ffsll((long long)sx_stop[w]) - 1;
+                    if (fneg < 0 && sx_neg[w]) fneg = w * gpw + ((__ffsll((long long)sx_neg[w]) - 1) >> lsh);
+                    if (fstop < 0 && sx_stop[w]) fstop = w * gpw + ((__ffsll((long long)sx_stop[w]) - 1) >> lsh);
                     if (fhard < 0 && sx_hard[w]) {
-                        fhard = w * WAVE + __ffsll((long long)sx_hard[w]) - 1;
+                        fhard = w * gpw + ((__ffsll((long long)sx_hard[w]) - 1) >> lsh);
                         hcode = -sx_hst[w];
                     }
                 }
@@ -703,23 +744,23 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                     if (lead) eg_fail(b, draw, it, ist, hcode);
                     return;
                 }
-                const bool kept = gl < take && r.status == 0 && isfinite(r.M);
+                const bool kept = rep && gl < take && r.status == 0 && isfinite(r.M);
                 {   // phase 2
                     const unsigned long long keptm = __ballot(kept);
-                    const unsigned long long infm = __ballot(gl < take && r.status == 2);
+                    const unsigned long long infm = __ballot(rep && gl < take && r.status == 2);
                     // evaluations of the consumed calls (and of the c1<=0 call, if it is next)
-                    int c = (gl < take || (negnext && gl == fneg)) ? r.cnt : 0;
+                    int c = (rep && (gl < take || (negnext && gl == fneg))) ? r.cnt : 0;
                     for (int o = WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
                     if (lane == 0) {
                         sx_kept[wave] = keptm;
                         sx_inf[wave] = infm;
                         sx_cnt[wave] = c;
                     }
-                    if (take > 0 && gl == take - 1) {
+                    if (rep && take > 0 && gl == take - 1) {
                         sx_take[0] = An;
                         sx_take[1] = r.R;
                     }
-                    if (negnext && gl == fneg) {
+                    if (rep && negnext && gl == fneg) {
                         sx_neg4[0] = An;
                         sx_neg4[1] = r.bshock;
                         sx_neg4[2] = r.bcash;
@@ -759,10 +800,12 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
                     ncalls += take;
                 }
                 keep = 1;
+                if (!negnext && take == ncan) small = 0;  // (consumed whole, no signal: back to a guess per lane)
                 if (negnext) {  // the next call hit c1<=0 (:583-621): prepare the resend
 #ifdef EGDST_FIXSTAT
                     fs_resend++;
 #endif
+                    small = FIX_LPG_SHIFT > 0 ? 1 : 0;
                     seq_left = EG_SEQ_AFTER_RESEND;
                     ms_pv nb;
                     nb.it = it + 1;
@@ -815,6 +858,7 @@ static __device__ __forceinline__ void eg_adraw_cycle(BatchRef b, int it, int dr
             evfa0 = -INFINITY;
             M = bcash;
             if (st == 1) {
+                small = (full && FIX_LPG_SHIFT > 0) ? 1 : 0;
                 seq_left = EG_SEQ_AFTER_RESEND;
                 ms_pv nb;
                 nb.it = it + 1;
@@ -1022,31 +1066,6 @@ __global__ void __launch_bounds__(GRID_BS) k_grid(const Batch *bp_, int it)
 static __device__ __forceinline__ int eg_second_bracket(double x, int i, double m2, double mlast2, int n1)
 {
     return (x < m2) ? 0 : ((x >= mlast2) ? n1 - 3 : i - 1);
-}
-
-// eg_bracket(x, g, n, 0) on a NON-DECREASING column without NaN (the caller checked the order): bxsearch_common (egdst_lib.c:136-166)
-// returns 0 below g[1], n-2 from g[n-2] on, and between them the last row that is not above x -- on an ordered column that is
-// "the last row i in [1, n-2] with g[i] <= x, or 0", however it is found.  Here: the branch-free form of the bisection -- the
-// range [base, base+len) shrinks by len/2 per step whatever the comparison says, so every lane makes the SAME number of steps (n
-// is uniform over the workgroup) and a step is one LDS read, one compare and one select.  The reference's loop compiled to ~22
-// instructions per step, 13 of them scalar bookkeeping of the lanes that had finished (profiles/r04_*: k_grid_lds_cv 5876
-// instructions, 2981 scalar).  A NaN x fails every comparison of the reference and its bisection runs up to row n-3: the same here.
-template <class P> static __device__ __forceinline__ int eg_last_le(double x, P g, int nrows)  // last row of [0, nrows) with g <= x, or 0
-{
-    P p = g;  // (the position as a pointer: one add per step, no index-to-address shift)
-    for (int len = nrows; len > 1;) {
-        const int half = len >> 1;
-        P q = p + half;
-        const double gj = *q;
-        p = (gj <= x) ? q : p;
-        len -= half;
-    }
-    return (int)(p - g);
-}
-template <class P> static __device__ __forceinline__ int eg_bracket_sorted(double x, P g, int n)
-{
-    const int i = eg_last_le(x, g, n - 1);  // rows 0 .. n-2
-    return (x != x) ? n - 3 : i;
 }
 
 // eg_bracket(x, g, n, 0) on a NON-DECREASING column, starting from a hint: the bracket of a neighbouring asset point for the
@@ -2663,6 +2682,9 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             if (toi >= j.ocap || toj >= j.nthrhmax) ok = 0;      // a full grid or threshold list: the sequential walk reports it
             sg_n = ok ? nseg : 0;
             atomicAdd(&j.segstat[ok ? 0 : 1], 1u);
+#ifdef EGDST_CENSUS
+            cz_sh_fb = ok ? 1 : 2;
+#endif
         }
         __syncthreads();
         if (sg_n) {
@@ -3786,6 +3808,11 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     // consumption column stays where it is: the walk copies it to the rows it keeps and reads it at a kink only.
     // A stream that does not fit (a degenerate guess stream with thousands of points) is k_envelope's.
     int we = 0, wn = 0, wm = 0;
+#ifdef EGDST_CENSUS
+    const unsigned long long cz_w0_ = wall_clock64();
+    if (tid == 0) cz_sh_fb = 0;
+    __syncthreads();
+#endif
     if (GLOBAL) {
         TWST(0);
         run_walk<0, true>(&E, job, b.qM + wo, b.qC + wo, b.qV + wo, b.qF + wo, b.rank + wo, b.gcls + wo, &we, &wn, &wm, classified);
@@ -3833,6 +3860,9 @@ static __device__ __forceinline__ void tp_walk(BatchRef b, int it, int stage, in
     run_walk<2, true>(&E, job, Lm, b.qC + wo, Lv, Lf, Lp, Lc, &we, &wn, &wm, classified);
     }
     TWST(1);
+#ifdef EGDST_CENSUS
+    if (tid == 0) EG_CENSUS(6, draw, it, stage | (big << 4), job.npts, job.nf | (cz_sh_fb << 16), wn, wall_clock64() - cz_w0_);
+#endif
     __syncthreads();  // (the results are wave 0's: hand them to the other waves of a fused kernel)
     if (tid == 0) S->res[0] = we, S->res[1] = wn, S->res[2] = wm;
     __syncthreads();

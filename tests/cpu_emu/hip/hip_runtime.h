@@ -116,6 +116,7 @@ static inline int atomicCAS(int *p, int cmp, int val) { return __sync_val_compar
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __sync_fetch_and_add(p, v); }
 static inline int atomicAdd(int *p, int v) { return __sync_fetch_and_add(p, v); }
 static inline int atomicOr(int *p, int v) { return __sync_fetch_and_or(p, v); }
+static inline int atomicExch(int *p, int v) { return __sync_lock_test_and_set(p, v); }
 static inline int atomicMin(int *p, int v)
 {
     int o = *p;

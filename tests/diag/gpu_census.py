@@ -88,6 +88,38 @@ for kind, name in ((2, 'k_envelope cells'), (1, 'k_envelope jobs'), (3, 'k_fixup
             print('   top: draw %5d it %2d id %d calls %5d skipped %5d kept %d  %9.1f us' % (x[1], x[2], x[3], x[4], x[5], x[6], us(x[7])))
     if kind == 5:
         print('   by (stage, error):', dict(zip(*[x.tolist() for x in np.unique(r[:, 3] * 100000 + r[:, 4], return_counts=True)])))
+# the walks of the throughput path: how much longer than its average workgroup does a launch's slowest one take?
+r = rec[rec[:, 0] == 6]
+if len(r):
+    ng = 16
+    grp = (np.searchsorted(np.arange(ng + 1) * nd // ng, r[:, 1], side='right') - 1)
+    for stage in (0, 1, 17):
+        q = r[r[:, 3] == stage]
+        if not len(q):
+            continue
+        g = grp[r[:, 3] == stage]
+        key = g.astype(np.int64) * 1000 + q[:, 2]
+        order = np.argsort(key, kind='stable')
+        ks, tk = key[order], us(q[order, 7].astype(np.float64))
+        bounds = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1], True])
+        mx = np.array([tk[a:b].max() for a, b in zip(bounds[:-1], bounds[1:])])
+        mean = np.array([tk[a:b].mean() for a, b in zip(bounds[:-1], bounds[1:])])
+        cnt = np.diff(bounds)
+        print('--- k_tp_walk stage %d%s: %d walks, per walk median %.1f us, mean %.1f, p99 %.1f, max %.1f; per (group, period) launch: walks %.0f, slowest walk median %.0f us, mean %.0f, p90 %.0f, max %.0f (its mean walk %.0f us); sum over periods of the slowest, per group: %.1f ms' % (
+            stage & 15, ' second tier' if stage & 16 else '', len(q), np.median(tk), tk.mean(), np.percentile(tk, 99), tk.max(), cnt.mean(), np.median(mx), mx.mean(),
+            np.percentile(mx, 90), mx.max(), mean.mean(), mx.sum() / ng / 1e3))
+        fb = (q[:, 5] >> 16) & 3
+        for code, name in ((0, 'one wave'), (1, 'segments merged'), (2, 'segments, then one wave again')):
+            w = q[fb == code]
+            if len(w):
+                print('   %-32s %7d walks, mean %.1f us, sum %.1f ms, rows out mean %.0f' % (name, len(w), us(w[:, 7].mean()), us(w[:, 7].astype(np.int64).sum()) / 1e3, w[:, 6].mean()))
+        top = q[np.argsort(-q[:, 7])[:8]]
+        for x in top:
+            print('   top: draw %5d it %2d points %5d functions %3d rows %5d mode %d  %8.1f us' % (x[1], x[2], x[4], x[5] & 0xffff, x[6], (x[5] >> 16) & 3, us(x[7])))
+        slow = q[us(q[:, 7]) > 150]
+        if len(slow):
+            print('   walks over 150 us: %d, functions median %d, rows out median %d, modes %s' % (len(slow), np.median(slow[:, 5] & 0xffff), np.median(slow[:, 6]),
+                  dict(zip(*[x.tolist() for x in np.unique((slow[:, 5] >> 16) & 3, return_counts=True)]))))
 # which draws own the k_envelope time
 r = rec[rec[:, 0] == 2]
 if len(r):
