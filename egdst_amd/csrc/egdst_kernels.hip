@@ -3676,18 +3676,6 @@ __global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort(const Batc
     __shared__ TpShared S;
     tp_sort(EG_BATCH_REF(bp_), it, stage, lkcap, wcap, (int)blockIdx.x, &S, (double *)dynlds, 0, bigcap, biglist, bigcnt);
 }
-// the second tier of stage 1: a small grid loops over the listed cells
-__global__ void __launch_bounds__(TP_SORT_BS, TP_SORT_MINW) k_tp_sort_big(const Batch *bp_, int it, int lkcap, const int *biglist, const int *bigcnt)
-{
-    EG_DYN_LDS(dynlds);
-    __shared__ TpShared S;
-    const int n = *bigcnt;
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        tp_sort(EG_BATCH_REF(bp_), it, 1, lkcap, lkcap, biglist[k], &S, (double *)dynlds, 1);
-        __syncthreads();  // (the LDS of the cell is reused by the next one)
-    }
-}
-
 // One wave per job.  stage 0: secondary envelope of a folded choice list, result written over the list it came from (dead by
 // then: its pieces live in the s slice, the sorted stream in the q slice); stage 1: primary envelope into the period's table.
 #ifndef TP_WALK_MINW
@@ -3908,14 +3896,21 @@ __global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk(const Batc
     __shared__ TpShared S;
     tp_walk<false>(EG_BATCH_REF(bp_), it, stage, list, cnt, lcap, (int)blockIdx.x, &S, (double *)dynlds);
 }
-__global__ void __launch_bounds__(TP_WALK_BS, TP_WALK_MINW) k_tp_walk_big(const Batch *bp_, int it, int *list, int *cnt, int lcap, const int *biglist,
-                                                                          const int *bigcnt)
+// The second tier of stage 1 in ONE launch: a workgroup sorts a listed cell's lists and walks them (the sort's 12 B per point,
+// then the walk's 24 B per point, in the same dynamic LDS).  Two launches -- k_tp_sort_big, then a walk kernel -- put two more
+// kernel latencies and launch gaps, ~110 us, on every group's chain every period for a handful of cells (tests/diag/gpu_group_finish.py).
+// TP_SORT_BS threads: the sort's size; the walk loads with all of them and walks with up to four waves as it does elsewhere.
+__global__ void __launch_bounds__(TP_SORT_BS, TP_WALK_MINW) k_tp_big(const Batch *bp_, int it, int *list, int *cnt, int cap, const int *biglist,
+                                                                     const int *bigcnt)
 {
     EG_DYN_LDS(dynlds);
     __shared__ TpShared S;
     const int n = *bigcnt;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        tp_walk<false>(EG_BATCH_REF(bp_), it, 1, list, cnt, lcap, biglist[k], &S, (double *)dynlds, 1);
+        tp_sort(EG_BATCH_REF(bp_), it, 1, cap, cap, biglist[k], &S, (double *)dynlds, 1);
+        __threadfence_block();  // (the sorted stream goes through global memory from one phase to the next)
+        __syncthreads();
+        tp_walk<false>(EG_BATCH_REF(bp_), it, 1, list, cnt, cap, biglist[k], &S, (double *)dynlds, 1);
         __syncthreads();  // (the LDS of the cell is reused by the next one)
     }
 }

@@ -102,7 +102,7 @@ def test_solution_import_serves_simulator_and_accessor(args):
     (['retirement2', 'T=8, ngridm=200, nthrhmax=200'], {}),                         # walks cut into segments (four walking waves)
     (['occ3', 'T=6, ngridm=30, ngridmax=100'], {'EGDST_TP_SORT_LKCAP': '16'}),       # sampled key index, permutation through global memory
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIG': '0'}),   # streams beyond the walk's LDS: left to k_envelope
-    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # ... done by the second tier of stage 1 (k_tp_sort_big, k_tp_walk_big)
+    (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40'}),             # ... done by the second tier of stage 1 (k_tp_big)
     (['retirement8', 'T=5, ngridm=30, ny=3'], {'EGDST_TP_LKCAP': '40', 'EGDST_TP_BIGCAP': '52'}),  # ... some by the second tier, the longest by k_envelope
 ])
 def test_throughput_path_of_the_envelope_step(args, env):
