@@ -83,5 +83,7 @@ WORKLOADS = {'C1': c1, 'C2': c2, 'C3': c3, 'C4': c4, 'C5': c5}
 #    With it -DGRID_MINW=8 pays for C2 as well (64 VGPRs, four 8-wave workgroups per CU): grid kernel 49.9 -> 45.1 ms, solve 162 -> 158 ms.
 #    (Round 4: 1024-point workgroups, one per stream, which then list the stream for k_fixup themselves instead of a k_fixup_scan
 #    launch: 169.8 ms against 167.1 for C2 a0=-5 x 4096 -- the scan launch costs nothing a chain notices; not kept.)
-BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3', '-DGRID_BS=512', '-DEG_GRID_CV_DEFAULT=1', '-DGRID_MINW=8'], 'C4': ['-DGRID_MINW=8', '-DGRID_BS=1024'], 'C5': ['-DGRID_MINW=8']}
+#  * C5, round 4: -DGRID_BS=1024 as well (with the branch-free searches the longer staging of a larger index is shared by four times the
+#    points: C5 x 128 3.28 -> 3.22 s; 512 points per workgroup: 3.36 s).
+BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3', '-DGRID_BS=512', '-DEG_GRID_CV_DEFAULT=1', '-DGRID_MINW=8'], 'C4': ['-DGRID_MINW=8', '-DGRID_BS=1024'], 'C5': ['-DGRID_MINW=8', '-DGRID_BS=1024']}
 BATCH_BUILD_MIN_DRAWS = {'C2': 1024, 'C4': 16, 'C5': 64}

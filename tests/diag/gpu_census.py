@@ -11,12 +11,16 @@ a0 = float(sys.argv[1]) if len(sys.argv) > 1 else -5.0
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 var = sys.argv[3] if len(sys.argv) > 3 else 'batch'
 pert = int(sys.argv[4]) if len(sys.argv) > 4 else -1   # >= 0: the draws moved by 0.5 % with this seed (gpu_groups_sweep.py, bench.py)
-m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
-_, gen = workloads.c2(a0=0)
-P = gen(nd)
+wl = os.environ.get('EGDST_DIAG_WL', 'C2')   # C2 (the a0 of argv), or a stress workload: C5, C4, C3 with its own draws
+if wl == 'C2':
+    m = examples.retirement_sig(T=60, ngridm=1000, ngridmax=10000, nthrhmax=1000, ny=10, a0=a0)
+    _, gen = workloads.c2(a0=0)
+else:
+    m, gen = workloads.WORKLOADS[wl]()
+P = gen(nd) if gen else np.tile(m.param_vector(), (nd, 1))
 if pert >= 0:
     P = P * (1 + 0.005 * (2 * np.random.default_rng(pert).random(P.shape) - 1))
-flags = (workloads.BATCH_BUILD_FLAGS['C2'] if var == 'batch' else []) + ['-DEGDST_CENSUS']
+flags = (workloads.BATCH_BUILD_FLAGS.get(wl, []) if var == 'batch' else []) + ['-DEGDST_CENSUS']
 lib = build.build_model(m, extra_flags=flags)
 L = lib.lib
 L.egdst_census_read.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -30,7 +34,7 @@ buf = np.zeros((cap, 8), dtype=np.int32)
 n = L.egdst_census_read(buf.ctypes.data, cap, 1)
 rec = buf[:min(n, cap)]
 st = s.status()[0]
-print('a0=%g ndraw=%d flags=%s: %.1f ms, failed %d, census records %d, tp done/left %s' % (a0, nd, flags, ms, int((st != 0).sum()), n, s.tp_stats().sum(axis=0).tolist()))
+print(wl, 'a0=%g ndraw=%d flags=%s: %.1f ms, failed %d, census records %d, tp done/left %s' % (a0, nd, flags, ms, int((st != 0).sum()), n, s.tp_stats().sum(axis=0).tolist()))
 codes, cnts = np.unique(st[st != 0], return_counts=True)
 print('failure codes:', dict(zip(codes.tolist(), cnts.tolist())))
 us = lambda x: x * 0.01   # ticks of 10 ns -> us
@@ -91,7 +95,7 @@ for kind, name in ((2, 'k_envelope cells'), (1, 'k_envelope jobs'), (3, 'k_fixup
 # the walks of the throughput path: how much longer than its average workgroup does a launch's slowest one take?
 r = rec[rec[:, 0] == 6]
 if len(r):
-    ng = 16
+    ng = s.schedule()[0]
     grp = (np.searchsorted(np.arange(ng + 1) * nd // ng, r[:, 1], side='right') - 1)
     for stage in (0, 1, 17):
         q = r[r[:, 3] == stage]
