@@ -607,7 +607,8 @@ class egdstmodel:  # noqa: N801  (reference class name)
         self.dbgout = getattr(sol, 'dbgout', None)
         self._solution = sol
         self.M, self.D = sol.cells()
-        self.__dict__['_solver_cells'] = (id(self.M), id(self.D))  # the live handle holds exactly these cells (runtime.py)
+        from . import runtime as _rt
+        self.__dict__['_solver_cells'] = (self.M, self.D, _rt._cells_stamp(self.M, self.D))  # the live handle holds exactly these cells (runtime.py)
         return sol
 
     def sim(self, *args):

@@ -550,6 +550,23 @@ def solve_model(model, dbgout=False):
     return sol
 
 
+def _cells_stamp(M, D):
+    """A cheap fingerprint of the cell arrays (shape and the bytes of the first, middle and last entry of every cell), so that a cell
+    REPLACED inside model.M / model.D -- which keeps the outer objects -- is noticed and the cells are uploaded again: the reference
+    reads them from the model object on every call.  (Bytes, not floats: a NaN entry must compare equal to itself.)"""
+    out = []
+    for cells in (M, D):
+        for row in cells:
+            for c in row:
+                if c is None:
+                    out.append(None)
+                    continue
+                a = np.asarray(c)
+                n = a.size
+                out.append((a.shape, a.flat[[0, n // 2, n - 1]].tobytes() if n else b''))
+    return tuple(out)
+
+
 def _solver_with_solution(model):
     """The handle that serves `sim` and `call`.  The reference's gateways take the solution from the model object on every
     call (egdst_simulator.c:61-68, egdst_call.c:28-34), not from the solve that produced it: when the handle of the last
@@ -558,7 +575,8 @@ def _solver_with_solution(model):
     if model.M is None or model.D is None:
         raise EgdstRuntimeError(40, 'Error: the model has not yet been solved!')
     s = model.__dict__.get('_solver')
-    if s is not None and model.__dict__.get('_solver_cells') == (id(model.M), id(model.D)):
+    held = model.__dict__.get('_solver_cells')   # the very objects the live handle holds (strong references: an id can be reused)
+    if s is not None and held is not None and held[0] is model.M and held[1] is model.D and held[2] == _cells_stamp(model.M, model.D):
         s.set_params(model.param_vector())   # loadparameters() of the gateways: the CURRENT values (after a setparam too)
         return s
     if s is not None:
@@ -567,7 +585,7 @@ def _solver_with_solution(model):
     s.set_params(model.param_vector())   # (loadparameters() of the gateways: the CURRENT parameter values)
     s.set_cells(model.M, model.D, draw=0)
     model.__dict__['_solver'] = s
-    model.__dict__['_solver_cells'] = (id(model.M), id(model.D))
+    model.__dict__['_solver_cells'] = (model.M, model.D, _cells_stamp(model.M, model.D))
     return s
 
 

@@ -158,6 +158,11 @@ static inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t s
 }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipMemset2DAsync(void *d, size_t pitch, int v, size_t w, size_t h, hipStream_t)
+{
+    for (size_t r = 0; r < h; r++) memset((char *)d + r * pitch, v, w);
+    return 0;
+}
 
 #if WAVE > 1
 #define EMU_WAVE_INIT(n) for (unsigned w_ = 0; w_ < ((n) + WAVE - 1) / WAVE && w_ < EMU_MAX_WAVES; w_++) pthread_barrier_init(&emu_wave_barrier[w_], nullptr, WAVE)

@@ -441,6 +441,38 @@ def test_import_solution_then_simulate_and_call_without_solving(name, how):
         h.close()
 
 
+def test_import_state_is_per_draw():
+    """A handle that was never solved and received the cells of ONE draw simulates that draw only: the others keep status
+    EGDST_E_NOT_SOLVED (they would otherwise simulate from empty tables); and the first import into a draw whose solve FAILED clears
+    the failed solve's other cells, so a half-imported draw is the import plus empty cells, never a mixture."""
+    m = examples.retirement2()
+    s = gpu_solve(m)
+    sol = s.solution(0)
+    f = runtime.Solver(s.lib, m.descriptor(), ndraw=3, keep_history=True)
+    f.set_params(np.tile(m.param_vector(), (3, 1)))
+    f.set_solution(sol, draw=1)
+    assert f.status()[0].tolist() == [40, 0, 40]
+    assert np.array_equal(f.checksums(1), s.checksums(0))
+    f.close()
+    s.close()
+    m, gen = workloads.c2(a0=0)
+    P = gen(1024)[[0, DEGENERATE[0]]]
+    g = gpu_solve(m, P)
+    nt, nst = g.nt, g.lib.info.nst
+    assert g.status()[0][0] == 0 and g.status()[0][1] != 0
+    good, bad = g.solution(0), g.solution(1)
+    assert bad.len.sum() > 0        # (the failed draw stopped in the middle: its later periods hold tables)
+    before = g.checksums(0).copy()
+    it, ist = nt - 1, 0
+    c = np.asfortranarray(g.cell_M(0, it, ist))
+    g.lib.check(g.lib.lib.egdst_set_cell_M(g.h, 1, it, ist, c.shape[0], c.ctypes.data_as(runtime.C.POINTER(runtime.C.c_double))))
+    assert g.status()[0].tolist() == [0, 0]
+    h = g.solution(1)
+    assert h.len[it, ist] == c.shape[0] and h.len.sum() == c.shape[0] and h.thlen.sum() == 0
+    assert np.array_equal(g.checksums(0), before)   # the other draw is untouched
+    g.close()
+
+
 def test_import_rejects_what_does_not_fit():
     m = examples.retirement2()
     s = gpu_solve(m)
@@ -474,6 +506,15 @@ def test_class_surface_sim_and_call_from_assigned_cells():
     m2.M, m2.D = sol.cells()        # e.g. read back from disk
     m2.randstream = m.randstream
     assert np.array_equal(m2.sim(init), sims, equal_nan=True)
+    assert np.array_equal(m2.call('vf', [[m.t0 + 3, 1, 2.5]]), vf)
+    # a cell replaced INSIDE the restored lists is noticed too (the reference reads the cells on every call)
+    it, ist = 3, 0
+    old = m2.M[ist][it]
+    changed = old.copy()
+    changed[:, 3] += 1.0            # the value column of one table
+    m2.M[ist][it] = changed
+    assert not np.array_equal(m2.call('vf', [[m.t0 + 3, 1, 2.5]]), vf)
+    m2.M[ist][it] = old
     assert np.array_equal(m2.call('vf', [[m.t0 + 3, 1, 2.5]]), vf)
     ref = Oracle(m)
     rsol = ref.solve()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC passes of one bench configuration on the GPU box (run through gpurun from the repo root):
 #   bash tools/pmc_run.sh <tag> <bench args ...>
-# Each pass is its own rocprofv3 run with --kernel-trace only (the program directly after --), as the pool requires.
+# Each pass is its own rocprofv3 run: --pmc <counters> with --kernel-trace and nothing else (no sys/hip/hsa trace domains), the program
+# directly after --, as the pool requires.  Pass --no-cpu-baseline among the bench arguments: no CPU pool under the profiler.
 set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
