@@ -35,14 +35,15 @@ struct Batch {
     Geom g;
     int draw0;           // first schedule slot of the group this launch works on (groups run on their own streams)
     const int *order;    // [ndraw] schedule: slot -> draw (identity until the host re-balances, egdst_host.inc)
-    struct Env1Scratch *e1sc;  // single-choice models: per (slot, state) scratch of the k_env1_* kernels
-    int *e1first, *e1cnt;      // first stopping candidate; rows per workgroup [E1 workgroups per cell]
-    int *tsorted;        // [ndraw*MS_NST] the M column of the next-period table of (draw, state) is in order (k_sortcheck)
+    struct Env1Tile *e1tiles;  // single-choice models: per (slot, state, tile) descriptors of k_env1
+    unsigned *e1done;          // [ndraw*MS_NST] tiles of the cell that have finished (counts on over the periods of a solve)
+    int *tsorted;        // [ndraw*MS_NST] stamp of the last period in which k_sortcheck found the next-period table of (draw, state) out of order
     int *negflag;        // [(draw*MS_NST+ist)*MS_ND+id] a grid point of the stream signalled c1<=0 (set by k_grid)
     int *fixn;           // [MAX_GROUPS * nt] streams listed for k_fixup per (group, period)
     int *fixlist;        // [ndraw*MS_NST*MS_ND] the lists, a group's at its first slot
     unsigned *work;      // [ndraw] re-basing calls of the draw's guess streams in this solve (straggler detection)
-    int sorted_valid;    // 1: k_sortcheck has filled tsorted for the tables of the next period before the kernels of this period
+    int sorted_valid;    // != 0: k_sortcheck runs before the kernels of every period and stamps tsorted[cell] with sorted_valid + it
+                         // when the next-period table of the cell is NOT in order (eg_tab_sorted); the base differs from solve to solve
     unsigned *nregen;    // [ndraw] guess streams of the draw that k_fixup regenerated in this solve (schedule: such draws share groups)
     const double *par;   // [ndraw][MS_NPARAM]
     const double *qw;    // [ny] weights
@@ -103,7 +104,7 @@ typedef const __attribute__((address_space(4))) Batch &BatchRef;
 #define EG_BATCH_REF(bp) (*(const __attribute__((address_space(4))) Batch *)(bp))
 #endif
 
-struct Env1Scratch;
+struct Env1Tile;
 #define TP_NF 64   // functions (choices, or the monotone pieces of one choice list) the throughput path of the envelope step keeps
 struct TpRec {     // what k_tp_prep found for one (cell, choice); k_tp_walk (secondary) updates cnt
     int active;    // the choice is in the choice set
@@ -283,6 +284,11 @@ template <class PD> struct TabT {
 typedef TabT<const double *> Tab;    // in global memory
 typedef TabT<const eg_ldsd *> TabL;  // M, C, V staged in LDS (k_fixup's sequential stretches)
 
+// the M column of the next-period table of (draw, ist) is known to be in order in period `it` (k_sortcheck; Batch::sorted_valid)
+static __device__ __forceinline__ int eg_tab_sorted(BatchRef b, int it, int draw, int ist)
+{
+    return b.sorted_valid != 0 && b.tsorted[(size_t)draw * MS_NST + ist] != b.sorted_valid + it;
+}
 static __device__ __forceinline__ Tab eg_tab(BatchRef b, int slot, int draw, int ist)
 {
     size_t k = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;

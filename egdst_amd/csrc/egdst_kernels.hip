@@ -257,7 +257,7 @@ static __device__ __forceinline__ LaneEval eg_lane_eval(BatchRef b, const ms_env
             break;
         }
         // the M column is known to be in order: k_sortcheck ran this period, or the caller checked its staged copy
-        const int tsorted = lt ? lt_sorted : (b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + nxt.ist] : 0);
+        const int tsorted = lt ? lt_sorted : eg_tab_sorted(b, cur->it, draw, nxt.ist);
         for (int iy = 0; iy < niy; iy++) {
             double pr1;
             if (niy == 1) {
@@ -361,7 +361,7 @@ static __device__ __forceinline__ int eg_wave_expectation(BatchRef b, const ms_e
         }
         if (t.len < 2) return -10;
         if (t.len > b.g.Sp || t.thlen > b.g.nthrhmax || t.thlen < 1) return -2707;
-        const int tsorted = lt ? lt_sorted : (b.sorted_valid ? b.tsorted[(size_t)draw * MS_NST + ist1] : 0);  // (see eg_lane_eval)
+        const int tsorted = lt ? lt_sorted : eg_tab_sorted(b, cur->it, draw, ist1);  // (see eg_lane_eval)
         for (int base = 0; base < niy && status == 0; base += GW) {
             const int iy = base + lane;
             double pr1 = 0, c1 = 1.0, t_rhs = 0, t_evf = 0, shock = 0, cash = 0;
@@ -1218,23 +1218,24 @@ static __device__ __forceinline__ double eg_term_sampled(const ms_env *E, const 
     return c1;
 }
 
-// Is the M column of every next-period table non-decreasing?  One workgroup per (draw, state) of the group, once per
-// period, for the handles whose tables do not fit k_grid_lds' LDS (the staged form checks the order while staging).
+// Is the M column of every next-period table non-decreasing?  Once per period, for the handles whose tables do not fit
+// k_grid_lds' LDS (the staged form checks the order while staging).  A table is spread over workgroups of SORTCHK_ROWS rows
+// (one workgroup per table took 23 us per period on C4's 65 536 rows); a workgroup that finds a pair out of order -- or, the
+// first one, a table too short or too long for the one-search form -- stamps the table with this period's mark; eg_tab_sorted
+// reads "no stamp of this period" as "in order", so nothing is cleared between periods.
+#define SORTCHK_ROWS (4 * GRID_BS)
 __global__ void __launch_bounds__(GRID_BS) k_sortcheck(const Batch *bp_, int it)
 {
     BatchRef b = EG_BATCH_REF(bp_);
-    __shared__ int bad_;
-    const int ist = blockIdx.x % MS_NST, draw = b.order[b.draw0 + blockIdx.x / MS_NST];
+    const int ist = blockIdx.y % MS_NST, draw = b.order[b.draw0 + blockIdx.y / MS_NST];
     const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
     const Tab t = eg_tab(b, slot1, draw, ist);
-    if (threadIdx.x == 0) bad_ = 0;
-    __syncthreads();
-    int bad = 0;
-    for (int r = threadIdx.x; r + 1 < t.len; r += GRID_BS)
-        if (!(t.M[r] <= t.M[r + 1])) bad = 1;
-    if (bad) bad_ = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) b.tsorted[(size_t)draw * MS_NST + ist] = (t.len >= 4 && t.len <= b.g.Sp && !bad_) ? 1 : 0;
+    const int r0 = (int)blockIdx.x * SORTCHK_ROWS, r1 = min(t.len - 1, r0 + SORTCHK_ROWS);
+    int bad = (blockIdx.x == 0 && threadIdx.x == 0 && !(t.len >= 4 && t.len <= b.g.Sp)) ? 1 : 0;
+    if (t.len <= b.g.Sp)
+        for (int r = r0 + (int)threadIdx.x; r < r1; r += GRID_BS)
+            if (!(t.M[r] <= t.M[r + 1])) bad = 1;
+    if (bad) b.tsorted[(size_t)draw * MS_NST + ist] = b.sorted_valid + it;
 }
 
 #ifndef GRID_MINW
@@ -1296,7 +1297,7 @@ template <int PPL, bool CV = false> static __device__ __forceinline__ void eg_gr
             for (int s1 = 0; s1 < MS_NST; s1++) nfe += gl_off[s1] > 0;
             stride = (tot + lrows - nfe - 1) / max(lrows - nfe, 1);
             for (int s1 = 0; s1 < MS_NST && ok; s1++)
-                if (gl_off[s1] > 0 && !(b.sorted_valid && b.tsorted[(size_t)draw * MS_NST + s1])) ok = 0;
+                if (gl_off[s1] > 0 && !eg_tab_sorted(b, it, draw, s1)) ok = 0;
         }
         int acc = 0;
         for (int s1 = 0; s1 < MS_NST; s1++) {
@@ -3936,105 +3937,61 @@ __global__ void __launch_bounds__(TP_WALKG_BS, TP_WALK_MINW) k_tp_walk_g(const B
 
 // ---------------------------------------------------------------------------------------------
 // Single-choice models (MS_ND == 1, e.g. the Deaton family): in the regular case the "envelope" of a cell is the stop
-// rule, the keep rule and the removal of repeated grid values -- a stream compaction with nothing sequential in it,
-// which one workgroup per cell (k_envelope) does at the speed of one CU (C4: 65 536 points, 0.58 ms per period, 77 %
-// of a solve).  Three small kernels spread a cell over E1_NB workgroups instead:
-//   k_env1_a  first requested point whose returned M stops the stream (atomicMin per cell);
-//   k_env1_b  per workgroup: rows it will write, evaluations, and whether anything irregular turns up (a fold, a list
-//             out of order, a hard error, a zero-consumption signal, an empty list, a regenerated stream);
-//   k_env1_c  prefix over the workgroups' counts, rows written in place; cells flagged irregular are left untouched
-//             and handed to k_envelope (pass 1), which then behaves exactly as it always did.
+// rule (:1100,1150), the keep rule (:634) and the removal of repeated grid values (:1290-1298) -- a stream compaction with
+// nothing sequential in it, which one workgroup per cell (k_envelope) does at the speed of one CU (C4: 65 536 points,
+// 0.58 ms per period, 77 % of a solve).  k_env1 spreads a cell over TILES of E1_TILE candidates, one workgroup each, and does
+// the whole step in ONE pass over the candidates (rounds 2-3 had four kernels that read them three times: 146 us per period
+// of C4 x 32 against the 27 us its bytes take):
+//   * a tile finds its first candidate whose returned M stops the stream, counts the rows it will write (kept, and not a
+//     repeat of the previous kept grid value), its evaluations, and whether anything irregular turns up (a fold, a list out
+//     of order, a hard error, a zero-consumption signal left over);
+//   * it publishes (rows, stop seen, irregular) in its descriptor and reads the descriptors of the tiles before it (decoupled
+//     look-back: those have smaller block indices, so they are resident or done; the wait is bounded all the same, and a
+//     tile that gives up marks the cell irregular): no stop before it -> its rows go to the table at the prefix of the counts;
+//   * the LAST tile of a cell to finish (a counter) sums up: an irregular cell, an empty one (error 15), a full grid (error
+//     13), no room for the threshold (error 20) or the compact capacity are k_envelope's (pass 1, from the untouched candidates:
+//     b.defer; the rows already written are covered by the high-water mark); otherwise row 0, the lengths, the counters and the
+//     rows past the new end.
+// Descriptors carry the period's tag (it + 1), so nothing is cleared between periods; the host clears them once per solve.
 #if MS_ND == 1
+#ifdef EGDST_EMU
+#define E1_BS ENV_BS_EMU
+#else
 #define E1_BS 256
-struct Env1Scratch {  // per schedule slot and state, zeroed by the host before pass a (e1first: set to a large value)
-    int flags, n2;
-    unsigned long long evals;
+#endif
+#define E1_PT 4                    // consecutive candidates of a thread
+#define E1_TILE (E1_BS * E1_PT)    // candidates of a workgroup
+#define E1_D_STOP (1ull << 24)
+#define E1_D_IRR (1ull << 25)
+#define E1_SPIN_MAX (1 << 22)      // polls of one descriptor before a tile gives up (never expected: seconds)
+struct Env1Tile {  // per (schedule slot, state, tile)
+    unsigned long long desc;   // [63:32] tag of the period, [25] irregular, [24] stop seen, [23:12] zero-consumption signals, [11:0] rows
+    unsigned long long evals;  // evaluations of the tile's candidates (written before desc)
 };
-#define E1_IRREGULAR 1
+// Everything one workgroup tells another goes through agent-scope atomics (they are performed where all XCDs see them), ordered by
+// a wait for the issuing wave's own memory operations.  NOT through __threadfence(): on this part a release fence writes back the
+// XCD's whole L2 and an acquire fence invalidates it, and with 2048 workgroups streaming rows through those L2s three fences per
+// workgroup made the kernel 497 us per launch on C4 x 32 (measured, gpurun_out/trace_r04b) -- nothing but the atomics is shared here.
+#ifdef EGDST_EMU
+#define E1_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define E1_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define E1_WAIT() __sync_synchronize()
+#else
+#define E1_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define E1_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define E1_WAIT()                          \
+    do {                                   \
+        __asm__ volatile("" ::: "memory"); \
+        __builtin_amdgcn_s_waitcnt(0);     \
+        __asm__ volatile("" ::: "memory"); \
+    } while (0)
+#endif
 static __device__ __forceinline__ bool e1_kept(BatchRef b, const ProbeOut &P, size_t co, int n, int terminal)
 {
     if (terminal) return true;
     if (n == 0) return P.np != 0;
     return eg_sc_status(b.cSt[co + n]) == 0 && isfinite(b.cM[co + n]);
 }
-// candidate range [lo, hi) of workgroup blk of nb, for requested candidates 0..nreq
-static __device__ __forceinline__ void e1_range(int nreq, int blk, int nb, int *lo, int *hi)
-{
-    const int per = (nreq + 1 + nb - 1) / nb;
-    *lo = blk * per;
-    *hi = min(nreq + 1, *lo + per);
-}
-static __device__ __forceinline__ int e1_nreq(BatchRef b, const ProbeOut &P, int first, int terminal)
-{
-    if (terminal) return b.g.ngridm - 1;
-    const int navail = P.grid ? min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls) : 0;
-    return min(first, navail);
-}
-
-__global__ void __launch_bounds__(E1_BS) k_env1_a(const Batch *bp_, int it, int terminal, int *e1first, int nb)
-{
-    BatchRef b = EG_BATCH_REF(bp_);
-    const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
-    int *F = e1first + ((size_t)b.draw0 * MS_NST + cellslot);
-    if (b.status[draw] || terminal) return;
-    const ProbeOut P = b.probe[((size_t)draw * MS_NST + ist) * MS_ND];
-    if (!P.active || P.seq || !P.grid) return;
-    const size_t co = eg_cand(b, draw, ist, 0);
-    const int navail = min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls);
-    int lo, hi;
-    e1_range(navail, blockIdx.x, nb, &lo, &hi);
-    int first = 0x7fffffff;
-    for (int n = max(lo, 1) + (int)threadIdx.x; n < hi; n += E1_BS)
-        if (!(b.cM[co + n] < b.g.mmax)) {
-            first = n;
-            break;
-        }
-    for (int o = WAVE / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-    if ((threadIdx.x & (WAVE - 1)) == 0 && first != 0x7fffffff) atomicMin(F, first);
-}
-
-// rows written by candidates [lo, hi) of a cell: kept, and not a repeat of the previous kept grid value; flags folds etc.
-static __device__ __forceinline__ int e1_count(BatchRef b, const ProbeOut &P, size_t co, int lo, int hi, int terminal, int *flags,
-                                               int *n2, unsigned long long *ev, int write, double *oM, double *oC, double *oV, int d0)
-{
-    // every thread takes a contiguous chunk; the predecessor of its first kept point is found by scanning back
-    const int per = (hi - lo + E1_BS - 1) / E1_BS;
-    const int a = lo + (int)threadIdx.x * per, z = min(hi, a + per);
-    int cnt = 0;
-    bool have = false;
-    double pm = 0, pv = 0;
-    for (int n = a; n < z; n++) {
-        if (!write && n >= 1 && !terminal) {
-            const int sc = b.cSt[co + n], st = eg_sc_status(sc);
-            if (st < 0 || st == 1) *flags |= E1_IRREGULAR;  // hard error / c1<=0 left over: k_envelope reports it
-            if (st == 2) *n2 += 1;
-            *ev += (unsigned long long)eg_sc_count(sc);
-        }
-        if (!e1_kept(b, P, co, n, terminal)) continue;
-        const double m = b.cM[co + n], v = b.cV[co + n];
-        if (!have) {  // previous kept candidate of the cell, if any
-            for (int q = n - 1; q >= 0 && !have; q--)
-                if (e1_kept(b, P, co, q, terminal)) pm = b.cM[co + q], pv = b.cV[co + q], have = true;
-            if (!have) {  // first kept point of the cell
-                if (write) oM[d0 + cnt] = m, oC[d0 + cnt] = b.cC[co + n], oV[d0 + cnt] = v;
-                cnt++;
-                pm = m, pv = v, have = true;
-                continue;
-            }
-        }
-        if (!write) {
-            if (!terminal && (pm > m || pv > v)) *flags |= E1_IRREGULAR;           // the list folds back: secondary envelope
-            if (pm > m || (pm == m && pv < v)) *flags |= E1_IRREGULAR;             // not in comp1 order: general sort
-        }
-        if (m != pm) {
-            if (write) oM[d0 + cnt] = m, oC[d0 + cnt] = b.cC[co + n], oV[d0 + cnt] = v;
-            cnt++;
-        }
-        pm = m, pv = v;
-    }
-    return cnt;
-}
-
 // exclusive scan of one int per thread over the workgroup; *total = sum
 static __device__ __forceinline__ int e1_scan(int v, int *sh, int *total)
 {
@@ -4053,49 +4010,20 @@ static __device__ __forceinline__ int e1_scan(int v, int *sh, int *total)
     return ex;
 }
 
-__global__ void __launch_bounds__(E1_BS) k_env1_b(const Batch *bp_, int it, int terminal, Env1Scratch *sc, const int *e1first, int *blkcnt, int nb,
-                                                  int defer_all /* tests: treat every cell as irregular */)
+__global__ void __launch_bounds__(E1_BS) k_env1(const Batch *bp_, int it, int terminal, Env1Tile *tiles, unsigned *done, int nb, unsigned tag,
+                                                int defer_all /* tests: treat every cell as irregular */)
 {
     BatchRef b = EG_BATCH_REF(bp_);
-    __shared__ int sh[E1_BS];
-    const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
-    const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
-    Env1Scratch *S = sc + sslot;
-    if (b.status[draw]) return;
-    ms_env E = eg_env(b, draw);
-    ms_pv cur;
-    cur.it = it, cur.ist = ist, cur.id = 0, cur.cash = cur.savings = cur.shock = 0;
-    if (ms_feasible(&E, &cur) != 1) return;  // (k_env1_c writes the empty cell)
-    const ProbeOut P = b.probe[cell * MS_ND];
-    if (!P.active || P.seq || defer_all) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S->flags, E1_IRREGULAR);
-        return;
-    }
-    const size_t co = eg_cand(b, draw, ist, 0);
-    const int nreq = e1_nreq(b, P, e1first[sslot], terminal);
-    int lo, hi;
-    e1_range(nreq, blockIdx.x, nb, &lo, &hi);
-    int flags = 0, n2 = 0;
-    unsigned long long ev = 0;
-    const int cnt = e1_count(b, P, co, lo, hi, terminal, &flags, &n2, &ev, 0, nullptr, nullptr, nullptr, 0);
-    int total;
-    (void)e1_scan(cnt, sh, &total);
-    if (threadIdx.x == 0) blkcnt[sslot * nb + blockIdx.x] = total;
-    if (flags) atomicOr(&S->flags, flags);
-    if (n2) atomicAdd(&S->n2, n2);
-    if (ev) atomicAdd(&S->evals, ev);
-}
-
-__global__ void __launch_bounds__(E1_BS) k_env1_c(const Batch *bp_, int it, int terminal, Env1Scratch *sc, const int *e1first, const int *blkcnt, int nb)
-{
-    BatchRef b = EG_BATCH_REF(bp_);
-    __shared__ int sh[E1_BS];
+    __shared__ int sh[E1_BS], s_has[E1_BS];
+    __shared__ double s_lm[E1_BS], s_lv[E1_BS];
+    __shared__ int s_first, s_flags, s_n2, s_pre, s_dead, s_last, s_stoptile;
+    __shared__ unsigned long long s_ev;
     const int cellslot = blockIdx.y, ist = cellslot % MS_NST, draw = b.order[b.draw0 + cellslot / MS_NST];
     const size_t cell = (size_t)draw * MS_NST + ist, sslot = (size_t)b.draw0 * MS_NST + cellslot;
     const int tid = threadIdx.x, blk = blockIdx.x;
     const int slot = (b.g.nslots == 2) ? (it & 1) : it;
     const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
-    Env1Scratch *S = sc + sslot;
+    // (the three early exits are the same for every tile of a cell: no tile of such a cell reaches the counter)
     if (b.status[draw]) {
         if (blk == 0 && tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
@@ -4107,70 +4035,206 @@ __global__ void __launch_bounds__(E1_BS) k_env1_c(const Batch *bp_, int it, int 
         if (blk == 0 && tid == 0) b.tlen[tk] = b.tthlen[tk] = 0;
         return;
     }
-    int outn = 0, before = 0;
-    for (int k = 0; k < nb; k++) {
-        const int c = blkcnt[sslot * nb + k];
-        if (k < blk) before += c;
-        outn += c;
-    }
-    // anything k_envelope would treat differently goes to k_envelope: irregular lists, no point at all (error 15), a
-    // full grid (error 13), no room for the threshold (error 20), the compact capacity
-    if ((S->flags & E1_IRREGULAR) || outn == 0 || outn >= b.g.ngridmax || outn > b.g.Cp || 1 >= b.g.nthrhmax) {
+    const ProbeOut P = b.probe[cell * MS_ND];
+    if (!P.active || P.seq || defer_all) {  // a regenerated stream, an inactive choice (error 14): k_envelope's
         if (blk == 0 && tid == 0) b.defer[cell] = 1;
         return;
     }
-    const ProbeOut P = b.probe[cell * MS_ND];
+    Env1Tile *T = tiles + sslot * (size_t)nb;
+    const unsigned long long dtag = (unsigned long long)tag << 32;
     const size_t co = eg_cand(b, draw, ist, 0);
-    const int nreq = e1_nreq(b, P, e1first[sslot], terminal);
-    int lo, hi;
-    e1_range(nreq, blk, nb, &lo, &hi);
-    double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
-    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
-    // rows of this workgroup: count per thread once more (cheap), scan, then write in place
-    int fl = 0, n2_ = 0;
-    unsigned long long ev_ = 0;
-    const int cnt = e1_count(b, P, co, lo, hi, terminal, &fl, &n2_, &ev_, 0, nullptr, nullptr, nullptr, 0);
-    int total;
-    const int ex = e1_scan(cnt, sh, &total);
-    (void)e1_count(b, P, co, lo, hi, terminal, &fl, &n2_, &ev_, 1, oM, oC, oV, 1 + before + ex);
-    // rows past the new end of the table are zero (see k_envelope); every workgroup clears a slice
-    const int hw_rows = b.thw[tk], hw_th = b.thhw[tk];
-    for (int i = outn + 1 + blk * E1_BS + tid; i < hw_rows; i += nb * E1_BS) oM[i] = oC[i] = oV[i] = 0.0;
-    if (blk == 0) {
-        for (int i = 1 + tid; i < hw_th; i += E1_BS) oTH[i] = oD[i] = 0.0;
-        if (tid == 0) {
-            oTH[0] = b.g.a0;
-            oD[0] = 0;
-            oM[0] = b.g.a0;
-            oC[0] = 0;
-            oV[0] = (S->n2 > 0) ? -INFINITY : P.evfa0;
-            b.tlen[tk] = outn + 1;
-            b.tthlen[tk] = 1;
-            const unsigned long long evals = S->evals + (terminal ? 0ull : (unsigned long long)P.probe_evals);
-            if (evals) atomicAdd(&b.evals[draw], evals);
-            unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull;
-            if (!terminal) {
-                const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
-                const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
-                by += 24ull * (unsigned long long)b.tlen[k1] + 16ull * (unsigned long long)b.tthlen[k1];
-            }
-            atomicAdd(&b.algbytes[draw], by);
+    // candidates 0 .. navail may have been requested; those after the first whose M stops the stream were not
+    const int navail = terminal ? b.g.ngridm - 1 : (P.grid ? min(b.g.ngridm - 1, b.g.ngridmax - 1 - P.ncalls) : 0);
+    const int lo = blk * E1_TILE, hi = min(navail + 1, lo + E1_TILE);
+    if (tid == 0) s_first = 0x7fffffff, s_flags = 0, s_n2 = 0, s_ev = 0, s_pre = 0, s_dead = 0, s_last = 0, s_stoptile = 0x7fffffff;
+    const int a = lo + tid * E1_PT;
+    double m[E1_PT], v[E1_PT], c[E1_PT];
+    int st[E1_PT];
+#pragma unroll
+    for (int k = 0; k < E1_PT; k++) {
+        const int n = a + k;
+        m[k] = v[k] = c[k] = 0, st[k] = 0;
+        if (n < hi) {
+            m[k] = b.cM[co + n], v[k] = b.cV[co + n], c[k] = b.cC[co + n];
+            if (n >= 1 && !terminal) st[k] = b.cSt[co + n];
         }
     }
-}
-
-// the high-water marks of the cells the fast path completed (after k_env1_c: every workgroup has read the old marks)
-__global__ void k_env1_d(const Batch *bp_, int it, int ncells)
-{
-    BatchRef b = EG_BATCH_REF(bp_);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ncells) return;
-    const int ist = k % MS_NST, draw = b.order[b.draw0 + k / MS_NST];
-    const size_t cell = (size_t)draw * MS_NST + ist;
-    const int slot = (b.g.nslots == 2) ? (it & 1) : it;
-    const size_t tk = ((size_t)slot * b.g.ndraw + draw) * MS_NST + ist;
-    if (b.defer[cell] || b.status[draw]) return;
-    if (b.tlen[tk] > 0) b.thw[tk] = b.tlen[tk], b.thhw[tk] = 1;
+    __syncthreads();
+    if (!terminal) {
+        int f = 0x7fffffff;
+#pragma unroll
+        for (int k = E1_PT - 1; k >= 0; k--)
+            if (a + k < hi && a + k >= 1 && !(m[k] < b.g.mmax)) f = a + k;
+        if (f != 0x7fffffff) atomicMin(&s_first, f);
+    }
+    __syncthreads();
+    const int first = s_first, nreq = min(first, navail);  // (as if no tile before this one stopped the stream: see below)
+    // ---- this thread's candidates: kept?  the last kept one for the threads after it --------------------
+    bool kept[E1_PT];
+    int has = 0;
+    double lm = 0, lv = 0;
+#pragma unroll
+    for (int k = 0; k < E1_PT; k++) {
+        const int n = a + k;
+        kept[k] = false;
+        if (n >= hi || n > nreq) continue;
+        kept[k] = terminal ? true : (n == 0 ? P.np != 0 : (eg_sc_status(st[k]) == 0 && isfinite(m[k])));
+        if (kept[k]) has = 1, lm = m[k], lv = v[k];
+    }
+    s_has[tid] = has, s_lm[tid] = lm, s_lv[tid] = lv;
+    __syncthreads();
+    // the previous kept candidate of the cell, if any: in this tile (nearly always the thread before), else further back
+    bool have = false;
+    double pm = 0, pv = 0;
+    if (has) {
+        for (int t = tid - 1; t >= 0 && !have; t--)
+            if (s_has[t]) pm = s_lm[t], pv = s_lv[t], have = true;
+        for (int q = lo - 1; q >= 0 && !have; q--)
+            if (e1_kept(b, P, co, q, terminal)) pm = b.cM[co + q], pv = b.cV[co + q], have = true;
+    }
+    int cnt = 0, flags = 0, n2 = 0, rowmask = 0;
+    unsigned long long ev = 0;
+#pragma unroll
+    for (int k = 0; k < E1_PT; k++) {
+        const int n = a + k;
+        if (n >= hi || n > nreq) continue;
+        if (n >= 1 && !terminal) {
+            const int s_ = eg_sc_status(st[k]);
+            if (s_ < 0 || s_ == 1) flags |= 1;  // hard error / c1<=0 left over: k_envelope reports it
+            if (s_ == 2) n2 += 1;
+            ev += (unsigned long long)eg_sc_count(st[k]);
+        }
+        if (!kept[k]) continue;
+        if (!have) {  // first kept point of the cell
+            rowmask |= 1 << k, cnt++;
+            pm = m[k], pv = v[k], have = true;
+            continue;
+        }
+        if (!terminal && (pm > m[k] || pv > v[k])) flags |= 1;            // the list folds back: secondary envelope
+        if (pm > m[k] || (pm == m[k] && pv < v[k])) flags |= 1;           // not in comp1 order: general sort
+        if (m[k] != pm) rowmask |= 1 << k, cnt++;
+        pm = m[k], pv = v[k];
+    }
+    int total;
+    const int ex = e1_scan(cnt, sh, &total);
+    if (flags) atomicOr(&s_flags, flags);
+    if (n2) atomicAdd(&s_n2, n2);
+    if (ev) atomicAdd(&s_ev, ev);
+    __syncthreads();
+    // ---- publish, then look back -----------------------------------------------------------------
+    unsigned long long mine = dtag | (unsigned long long)total | ((unsigned long long)s_n2 << 12) | (first != 0x7fffffff ? E1_D_STOP : 0ull) |
+                              (s_flags ? E1_D_IRR : 0ull);
+    if (tid == 0) {
+        E1_STORE(&T[blk].evals, s_ev);
+        E1_WAIT();
+        E1_STORE(&T[blk].desc, mine);
+    }
+    if (tid < WAVE) {  // the first wave: lane j reads the descriptors j, j + WAVE, ... of the tiles before this one
+        int pre = 0, dead = 0, gaveup = 0;
+        for (int j0 = 0; j0 < blk && !dead && !gaveup; j0 += WAVE) {
+            const int j = j0 + tid;
+            unsigned long long d = dtag;
+            if (j < blk) {
+                int spins = 0;
+                d = E1_LOAD(&T[j].desc);
+                while ((d >> 32) != (unsigned long long)tag && ++spins < E1_SPIN_MAX) {
+#ifndef EGDST_EMU
+                    __builtin_amdgcn_s_sleep(2);
+#endif
+                    d = E1_LOAD(&T[j].desc);
+                }
+                if ((d >> 32) != (unsigned long long)tag) gaveup = 1, d = dtag;
+            }
+            int cj = (int)(d & 0xfffull);
+            for (int o = WAVE / 2; o > 0; o >>= 1) cj += __shfl_xor(cj, o);
+            pre += cj;
+            dead = __any((d & E1_D_STOP) != 0);
+            gaveup = __any(gaveup);
+        }
+        if (tid == 0) {
+            s_pre = pre, s_dead = dead;
+            if (gaveup) {  // (the tiles after this one used its rows and its stop flag only; the last tile reads the rest)
+                mine |= E1_D_IRR;
+                E1_STORE(&T[blk].desc, mine);
+                s_dead = 1;
+            }
+        }
+    }
+    __syncthreads();
+    double *oM = b.tM + tk * b.g.Sp, *oC = b.tC + tk * b.g.Sp, *oV = b.tV + tk * b.g.Sp;
+    if (!s_dead) {  // no tile before this one stopped the stream: its rows, in place
+        int row = 1 + s_pre + ex;
+#pragma unroll
+        for (int k = 0; k < E1_PT; k++)
+            if (rowmask & (1 << k)) {
+                if (row < b.g.Sp) oM[row] = m[k], oC[row] = c[k], oV[row] = v[k];
+                row++;
+            }
+    }
+    // ---- the last tile of the cell to get here finishes the cell ------------------------------------
+    __syncthreads();
+    if (tid == 0) {
+        E1_WAIT();  // (this tile's descriptor is where the last tile will look for it)
+        s_last = ((atomicAdd(&done[sslot], 1u) + 1u) % (unsigned)nb == 0u);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the tiles up to and including the first that saw a stop count; the others wrote nothing
+    for (int j = tid; j < nb; j += E1_BS)
+        if (E1_LOAD(&T[j].desc) & E1_D_STOP) atomicMin(&s_stoptile, j);
+    if (tid == 0) s_flags = 0, s_n2 = 0, s_ev = 0;
+    __syncthreads();
+    int outn = 0;
+    {
+        const int lastt = min(nb - 1, s_stoptile);
+        int rows = 0, fl = 0, z2 = 0;
+        unsigned long long e_ = 0;
+        for (int j = tid; j <= lastt; j += E1_BS) {
+            const unsigned long long d = E1_LOAD(&T[j].desc);
+            rows += (int)(d & 0xfffull), z2 += (int)((d >> 12) & 0xfffull), fl |= (d & E1_D_IRR) ? 1 : 0;
+            if ((d >> 32) != (unsigned long long)tag) fl |= 1;  // (never expected)
+            e_ += E1_LOAD(&T[j].evals);
+        }
+        int tot;
+        (void)e1_scan(rows, sh, &tot);
+        outn = tot;
+        if (fl) atomicOr(&s_flags, 1);
+        if (z2) atomicAdd(&s_n2, z2);
+        if (e_) atomicAdd(&s_ev, e_);
+        __syncthreads();
+    }
+    // anything k_envelope would treat differently goes to k_envelope: irregular lists, no point at all (error 15), a
+    // full grid (error 13), no room for the threshold (error 20), the compact capacity.  Rows of the table may have been
+    // written: the marks say "unknown", so that k_envelope clears everything past its own end.
+    if (s_flags || outn == 0 || outn >= b.g.ngridmax || outn > b.g.Cp || 1 >= b.g.nthrhmax) {
+        if (tid == 0) b.defer[cell] = 1, b.thw[tk] = b.g.Sp;
+        return;
+    }
+    double *oTH = b.tTH + tk * b.g.nthrhmax, *oD = b.tD + tk * b.g.nthrhmax;
+    // rows past the new end of the table are zero (see k_envelope)
+    const int hw_rows = b.thw[tk], hw_th = b.thhw[tk];
+    for (int i = outn + 1 + tid; i < hw_rows; i += E1_BS) oM[i] = oC[i] = oV[i] = 0.0;
+    for (int i = 1 + tid; i < hw_th; i += E1_BS) oTH[i] = oD[i] = 0.0;
+    __syncthreads();  // (every thread has read the old marks)
+    if (tid == 0) {
+        oTH[0] = b.g.a0;
+        oD[0] = 0;
+        oM[0] = b.g.a0;
+        oC[0] = 0;
+        oV[0] = (s_n2 > 0) ? -INFINITY : P.evfa0;
+        b.tlen[tk] = outn + 1;
+        b.tthlen[tk] = 1;
+        b.thw[tk] = outn + 1, b.thhw[tk] = 1;
+        const unsigned long long evals = s_ev + (terminal ? 0ull : (unsigned long long)P.probe_evals);
+        if (evals) atomicAdd(&b.evals[draw], evals);
+        unsigned long long by = 24ull * (unsigned long long)(outn + 1) + 16ull;
+        if (!terminal) {
+            const int slot1 = (b.g.nslots == 2) ? ((it + 1) & 1) : (it + 1);
+            const size_t k1 = ((size_t)slot1 * b.g.ndraw + draw) * MS_NST + ist;
+            by += 24ull * (unsigned long long)b.tlen[k1] + 16ull * (unsigned long long)b.tthlen[k1];
+        }
+        atomicAdd(&b.algbytes[draw], by);
+    }
 }
 #endif
 

@@ -109,6 +109,7 @@ static inline unsigned long long __ballot(int x)
 static inline int __any(int x) { return __ballot(x) != 0ull; }
 #endif
 static inline void __threadfence_block() { __sync_synchronize(); }
+static inline void __threadfence() { __sync_synchronize(); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
