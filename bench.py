@@ -144,11 +144,12 @@ CLASS_NAMES = ['probe', 'grid', 'k_envelope', 'regeneration', 'tp_prep', 'tp_sor
 # 'regen' = the guess streams k_fixup regenerated
 KERNELS = [('k_probe', ['k_probe'], [0], 'cells'),
            ('grid', ['k_grid_lds_cv', 'k_grid_lds', 'k_grid_wide', 'k_grid'], [1], 'cells'),
-           ('k_envelope', ['k_envelope'], [2], 'left'),
+           ('k_envelope', ['k_env1', 'k_envelope'], [2], 'left'),   # (single-choice models: k_env1 does the regular cells of the class)
            ('k_fixup', ['k_fixup'], [3], 'regen'),
            ('k_tp_prep', ['k_tp_prep'], [4], 'cells'),
            ('k_tp_sort', ['k_tp_sort', 'k_tp_sort_big'], [5, 6], 'cells'),
-           ('k_tp_walk', ['k_tp_walk', 'k_tp_walk_big'], [7, 8], 'cells')]
+           ('k_tp_walk', ['k_tp_walk', 'k_tp_big'], [7, 8], 'cells'),
+           ('k_sortcheck', ['k_sortcheck'], [], 'cells')]   # (no profile class of its own: launched once per period like k_probe)
 TRACE_ROUND = 'r04'
 
 
@@ -191,7 +192,7 @@ def roofline_record(key, kms, klaunch, algbytes, evals_step, value, ms_step, cel
         tns = sum(tr[k][1] for k in knames if k in tr)
         pm = next((pmc_cfg[k] for k in knames if k in pmc_cfg), {})
         kname = next((k for k in knames if k in tr or k in pmc_cfg), knames[0])
-        per[name] = dict(kernel=kname, covers=covers, ms16=ms16, n16=n16, ms1=ms1, n1=n1, trace_calls=tcalls, trace_ns=tns, pm=pm)
+        per[name] = dict(kernel=kname, knames=knames, covers=covers, ms16=ms16, n16=n16, ms1=ms1, n1=n1, trace_calls=tcalls, trace_ns=tns, pm=pm)
     if any(v['trace_ns'] for v in per.values()):
         dom, dom_by = max(per, key=lambda k: per[k]['trace_ns']), 'largest total duration in ' + tr_file
     elif serial_ms is not None:
@@ -218,9 +219,11 @@ def roofline_record(key, kms, klaunch, algbytes, evals_step, value, ms_step, cel
     traffic_step = None
     if pmc_cfg and any(v['pm'] for v in per.values()):
         traffic_step = 0.0
-        for v in per.values():
-            if v['pm'] and v['n16']:
-                traffic_step += v['pm']['hbm_bytes_per_launch'] * v['n16']
+        for name, v in per.items():
+            for k in v['knames']:   # every kernel of the class with its own counters (k_env1 and k_envelope; k_tp_walk and k_tp_big)
+                if k in pmc_cfg:
+                    n = pmc_cfg[k]['dispatches'] / max(pmc_cfg.get('k_probe', {}).get('dispatches', 0), 1) * per['k_probe']['n16']
+                    traffic_step += pmc_cfg[k]['hbm_bytes_per_launch'] * n
     grid_alone = float(serial_ms[1]) if serial_ms is not None else None
     egm_only = evals_step / (grid_alone * 1e-3) if grid_alone else None
     pg = per['grid']['pm']
@@ -241,7 +244,7 @@ def roofline_record(key, kms, klaunch, algbytes, evals_step, value, ms_step, cel
                      'frac': algbytes / (ms_step * 1e-3) / 1e9 / 8000.0, 'traffic_bytes': traffic_step,
                      'traffic_over_algorithmic': (traffic_step / algbytes) if (traffic_step and algbytes) else None,
                      'traffic_GBps': (traffic_step / (ms_step * 1e-3) / 1e9) if traffic_step else None, 'unit': 'GB/s',
-                     'note': 'traffic_bytes = sum over the kernels of (FETCH_SIZE + WRITE_SIZE per launch in the committed counter passes) x this run\'s launches'},
+                     'note': 'traffic_bytes = sum over the kernels of (FETCH_SIZE + WRITE_SIZE per launch in the committed counter passes) x their launches per k_probe launch there x this run\'s k_probe launches'},
             'ceilings': {'note': 'egm_only: the evaluations of a step / the device time of the grid kernel when it has the GPU to itself '
                                  '(one draw group, no concurrent streams); kernel_ms_one_group: every class measured that way',
                          'egm_only_evals_per_s': egm_only,
@@ -353,7 +356,7 @@ def timed_leg(workload, ndraw, model=None, drawgen=None, params=None, label=None
            'config': 'T=%d, ngridm=%d, ny=%d, nd=%d, nst=%d, a0=%g, mmax=%g' % (desc['T'], desc['ngridm'], desc['ny'], lib.info.nd,
                                                                                    lib.info.nst, desc['a0'], desc['mmax'])}
     out['roofline'] = roofline_record('%s_ndraw%d' % (counters_as or workload, chunk), kms, klaunch, algbytes, rec['ev_exec'] / max(len(plan), 1), value,
-                                      rec['dt'] * 1e3 / max(len(plan), 1), chunk * nst * nt, int(tps[:, 1].sum()) if lib.info.nd > 1 else chunk * nst * nt,
+                                      rec['dt'] * 1e3 / max(len(plan), 1), chunk * nst * nt, int(tps[:, 1].sum()) if (lib.info.nd > 1 and int(tps.sum()) > 0) else chunk * nst * nt,   # (no throughput path: every cell is k_envelope's)
                                       int(regen.sum()), serial_ms=serial_ms, serial_launch=serial_launch)
     if balance:
         out['shard_balance'] = balance
@@ -588,7 +591,7 @@ def main():
             'envelope_cells_by_throughput_path': main_extra['envelope_cells_by_throughput_path'],
             'roofline': roofline_record('%s_ndraw%d' % (args.workload, chunk), kms, klaunch, algbytes, ev_exec_all / args.steps / max(world * nchunks, 1),
                                         ev_exec_all / dt_max, ms_step / max(nchunks, 1), chunk * lib.info.nst * (desc['T'] - desc['t0'] + 1),
-                                        int(tps_last[:, 1].sum()) if lib.info.nd > 1 else chunk * lib.info.nst * (desc['T'] - desc['t0'] + 1),
+                                        int(tps_last[:, 1].sum()) if (lib.info.nd > 1 and int(tps_last.sum()) > 0) else chunk * lib.info.nst * (desc['T'] - desc['t0'] + 1),
                                         regen_last, small=args.small, serial_ms=serial_ms, serial_launch=serial_launch),
         }
         one = np.asarray(model.param_vector(), dtype=np.float64)[None] if mine_n else None   # fixed parameters: comparable from run to run

@@ -4645,6 +4645,11 @@ __global__ void k_math_eval(int fn, int n, const double *x, const double *y, dou
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fn >= 3) {  // the interpolation f0 (g1 - x) / (g1 - g0) + f1 (x - g0) / (g1 - g0): 3 the grid kernels' shared-reciprocal form, 4 the plain one
+        const double xq = x[i], g0 = x[n + i], g1 = x[2 * (size_t)n + i], f0 = y[i], f1 = y[n + i];
+        out[i] = fn == 3 ? eg_lerp_fast(xq, g0, g1, f0, f1) : eg_lerp(xq, g0, g1, f0, f1);
+        return;
+    }
     out[i] = fn == 0 ? MS_EXP(x[i]) : (fn == 1 ? MS_LOG(x[i]) : MS_POW(x[i], y[i]));
 }
 

@@ -117,6 +117,15 @@ class ModelLibrary:
         if rc != 0:
             raise EgdstRuntimeError(rc, (self.lib.egdst_last_error() or b'').decode(errors='replace'))
 
+    def lerp_eval(self, x, g0, g1, f0, f1, shared=True):
+        """linter's interpolation on the device: the grid kernels' shared-reciprocal form or the plain one (egdst_math_eval 3 / 4)."""
+        xs = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in (x, g0, g1)]))
+        ys = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in (f0, f1)]))
+        n = xs.size // 3
+        out = np.zeros(n)
+        self.check(self.lib.egdst_math_eval(3 if shared else 4, n, _dp(xs), _dp(ys), _dp(out)))
+        return out
+
     def math_eval(self, fn, x, y=None):
         """The device's exp ('exp'), log ('log'), pow ('pow') on host arrays (egdst_math_eval)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -240,7 +240,9 @@ int egdst_get_dbgout(egdst_handle *h, int draw, double *out /* [nt*nst*nd*2*nt *
 int egdst_get_checksums(egdst_handle *h, int draw, unsigned long long *out /* [nt*nst*5] */);
 
 /* Diagnostics: this library's device exp (fn 0), log (1), pow (2) on host arrays x, y (y only for pow), n values.
- * include/egdst_math.h restates glibc's algorithms so that these equal the host libm bit for bit. */
+ * include/egdst_math.h restates glibc's algorithms so that these equal the host libm bit for bit.
+ * fn 3, 4: the interpolation of linter (egdst_lib.c:186-189), f0 (g1 - x) / (g1 - g0) + f1 (x - g0) / (g1 - g0), in the form the grid
+ * kernels use (3: one refined reciprocal serves both quotients) and as written (4); x = [x | g0 | g1] (3n values), y = [f0 | f1] (2n). */
 int egdst_math_eval(int fn, int n, const double *x, const double *y, double *out);
 
 /* Envelope walks of the last solve per draw: out[2*draw] = walks that were cut into segments (one wave each) and merged,

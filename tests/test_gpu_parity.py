@@ -575,6 +575,50 @@ def test_device_math_equals_host_libm():
         assert np.array_equal(lib.math_eval('pow', np.abs(x), x / 7), np.array([m.pow(abs(v), v / 7) for v in x]))
 
 
+def test_shared_reciprocal_interpolation_is_the_ieee_expression():
+    """The grid kernels interpolate with ONE refined reciprocal for the two quotients of linter's expression (eg_lerp_fast, round 4).
+    On 4 million operand sets -- node spacings from 1e-13 to 1e4, abscissae inside and far outside the bracket, ordinates of both
+    signs up to 1e300, exact hits of a node (zero numerators) -- the device's result equals the host's IEEE evaluation of
+    f1 (x - g0) / (g1 - g0) + f0 (g1 - x) / (g1 - g0) (numpy: correctly rounded divisions, no contraction) bit for bit; and for
+    divisors outside the fast form's domain (below 2^-300, zero, negative, NaN) and results beyond the finite range it returns
+    what the plain device expression returns."""
+    lib = build.build_model(examples.retirement2())
+    rng = np.random.default_rng(2024)
+    n = 1 << 22
+    g0 = rng.uniform(-5, 50, n)
+    d = 10.0 ** rng.uniform(-13, 4, n)
+    g1 = g0 + d
+    x = np.where(rng.random(n) < 0.7, g0 + rng.random(n) * (g1 - g0), g0 + rng.normal(0, 5, n) * (g1 - g0))
+    mag = 10.0 ** rng.uniform(-8, 8, n)
+    f0, f1 = rng.normal(0, 1, n) * mag, rng.normal(0, 1, n) * mag
+    k = n // 16
+    x[:k] = g0[:k]                      # exact node: a zero numerator
+    x[k:2 * k] = g1[k:2 * k]
+    f0[2 * k:3 * k] *= 1e292            # large ordinates (finite results)
+    f1[2 * k:3 * k] *= 1e292
+    with np.errstate(all='ignore'):
+        want = f1 * (x - g0) / (g1 - g0) + f0 * (g1 - x) / (g1 - g0)
+    ok = np.isfinite(want) & ((g1 - g0) >= 2.0 ** -300)
+    got = lib.lerp_eval(x, g0, g1, f0, f1, shared=True)
+    assert ok.mean() > 0.99
+    assert np.array_equal(got[ok], want[ok])
+    plain = lib.lerp_eval(x, g0, g1, f0, f1, shared=False)
+    assert np.array_equal(plain[ok], want[ok])
+    # outside the domain of the fast form: whatever the plain expression gives on the device
+    m = 4096
+    g0 = rng.uniform(-5, 50, m)
+    g1 = g0.copy()
+    g1[: m // 4] = g0[: m // 4]                                  # zero divisor
+    g1[m // 4: m // 2] = g0[m // 4: m // 2] - 10.0 ** rng.uniform(-10, 2, m // 4)   # negative divisor
+    g0[m // 2: 3 * m // 4] = 0.0
+    g1[m // 2: 3 * m // 4] = 2.0 ** rng.uniform(-1070, -301, m // 4)   # tiny divisor
+    g1[3 * m // 4:] = np.nan
+    x = g0 + rng.normal(0, 1, m)
+    f0, f1 = rng.normal(0, 1e300, m), rng.normal(0, 1e300, m)
+    a, b = lib.lerp_eval(x, g0, g1, f0, f1, shared=True), lib.lerp_eval(x, g0, g1, f0, f1, shared=False)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize('name', ['retirement2', 'occ3', 'retire8', 'deaton2', 'model2', 'C2', 'C2_a0neg_T60', 'occ3_n400'])
 @pytest.mark.parametrize('lds', ['lds', 'lds_cv', 'sampled', 'general'])
 def test_batch_grid_kernels_on_single_draws(name, lds, monkeypatch):
