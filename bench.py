@@ -231,7 +231,10 @@ def roofline_record(key, kms, klaunch, algbytes, evals_step, value, ms_step, cel
     return {'bound': 'hbm', 'bound_note': 'reported against HBM as the contract asks; the path is latency / issue bound, see ceilings',
             'kernel': d['kernel'], 'kernel_class': dom, 'dominant_by': dom_by,
             'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': (achieved / 8000.0) if achieved is not None else None,
-            'traffic': pm.get('hbm_bytes_per_launch'),
+            # the counter passes ran the 16-group schedule (a launch = one group's cells); `achieved` is per ONE-GROUP launch (all cells):
+            # the same units, i.e. the counters' bytes per launch x the launches of the 16-group step per one-group launch
+            'traffic': (pm['hbm_bytes_per_launch'] * (d['n16'] / d['n1'] if (ach1 is not None and d['n1']) else 1.0)) if pm.get('hbm_bytes_per_launch') else None,
+            'traffic_per_launch_in_counter_pass': pm.get('hbm_bytes_per_launch'),
             'algorithmic_bytes_per_launch': bpl, 'avg_launch_ms': avg, 'launches': int(d['n1'] or d['n16']),
             'measured': 'HIP events around the launches of one more solve of the same draws with ONE draw group (the kernel has the GPU to itself), right after the timed region',
             'share_of_step_bytes': share,

@@ -1,13 +1,18 @@
 """Diagnostic: how evenly the draw groups of a C2 batch finish, and each group's summed kernel time per class (HIP events on the
-group streams, egdst_get_group_profile).   python tests/diag/gpu_group_finish.py [a0=-5] [ndraw=4096]"""
+group streams, egdst_get_group_profile).   python tests/diag/gpu_group_finish.py [a0=-5] [ndraw=4096]
+(EGDST_DIAG_WL=C5 / C4 / C3: that stress workload on its batch build instead; a0 is then ignored)"""
 import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
 a0 = float(sys.argv[1]) if len(sys.argv) > 1 else -5.0
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-m, gen = workloads.c2(a0=a0)
-lib = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS['C2'])
+import os
+wl = os.environ.get('EGDST_DIAG_WL', 'C2')
+m, gen = workloads.c2(a0=a0) if wl == 'C2' else workloads.WORKLOADS[wl]()
+if gen is None:
+    gen = lambda n: np.tile(m.param_vector(), (n, 1))
+lib = build.build_model(m, extra_flags=workloads.BATCH_BUILD_FLAGS.get(wl, []))
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
 s.set_params(gen(nd)); s.solve(raise_on_error=False); s.solve(raise_on_error=False)
 s.set_profile(True)
