@@ -4011,7 +4011,7 @@ static __device__ __forceinline__ int e1_scan(int v, int *sh, int *total)
 }
 
 __global__ void __launch_bounds__(E1_BS) k_env1(const Batch *bp_, int it, int terminal, Env1Tile *tiles, unsigned *done, int nb, unsigned tag,
-                                                int defer_all /* tests: treat every cell as irregular */)
+                                                int defer_all /* tests: 1 treat every cell as irregular, 2 find it irregular late */)
 {
     BatchRef b = EG_BATCH_REF(bp_);
     __shared__ int sh[E1_BS], s_has[E1_BS];
@@ -4036,7 +4036,7 @@ __global__ void __launch_bounds__(E1_BS) k_env1(const Batch *bp_, int it, int te
         return;
     }
     const ProbeOut P = b.probe[cell * MS_ND];
-    if (!P.active || P.seq || defer_all) {  // a regenerated stream, an inactive choice (error 14): k_envelope's
+    if (!P.active || P.seq || defer_all == 1) {  // a regenerated stream, an inactive choice (error 14): k_envelope's
         if (blk == 0 && tid == 0) b.defer[cell] = 1;
         return;
     }
@@ -4115,6 +4115,7 @@ __global__ void __launch_bounds__(E1_BS) k_env1(const Batch *bp_, int it, int te
         if (m[k] != pm) rowmask |= 1 << k, cnt++;
         pm = m[k], pv = v[k];
     }
+    if (defer_all == 2) flags |= 1;  // (tests: every cell is found irregular AFTER its tiles have written their rows)
     int total;
     const int ex = e1_scan(cnt, sh, &total);
     if (flags) atomicOr(&s_flags, flags);

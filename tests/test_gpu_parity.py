@@ -846,6 +846,44 @@ def test_walk_variants_agree_on_a_batch(monkeypatch):
             assert np.array_equal(x, y), k
 
 
+@pytest.mark.parametrize('mode', ['fast', 'defer_all', 'defer_late', 'off'])
+def test_single_choice_envelope_tiles_and_hand_over(mode, monkeypatch):
+    """k_env1 (round 4: one pass, tiles of 1024 candidates with decoupled look-back) on a batch of single-choice draws with five
+    tiles per cell and on deaton2 as shipped (regenerated streams: k_envelope's from the start): tables equal the oracle's bit for
+    bit with the history kept, and with two ping-pong periods status, evaluation counts and the checksums of the two live periods
+    equal the kept-history solve's -- on the fast path, with every cell handed to k_envelope before (EGDST_E1_DEFER_ALL=1) and AFTER
+    (=2) its tiles wrote rows into the table (the high-water marks must then cover them), and with k_env1 off."""
+    if mode == 'defer_all':
+        monkeypatch.setenv('EGDST_E1_DEFER_ALL', '1')
+    if mode == 'defer_late':
+        monkeypatch.setenv('EGDST_E1_DEFER_ALL', '2')
+    if mode == 'off':
+        monkeypatch.setenv('EGDST_NO_ENV1', '1')
+    m, gen = workloads.c4(ngridm=5000, T=12, ny=7)
+    P = gen(6)
+    orc = Oracle(m)
+    s = gpu_solve(m, P)
+    for d in range(len(P)):
+        ref = orc.solve(P[d])
+        sol = s.solution(d)
+        assert ref.rc == 0 and sol.status == 0
+        ok, rep = compare(sol, ref, rtol=0.0, th_tol=0.0)
+        assert ok, (d, rep)
+        assert sol.nevals == ref.nevals
+    p = gpu_solve(m, P, keep_history=False)     # two ping-pong slots: a slot's rows past the new end must be cleared every period
+    assert np.array_equal(p.status()[0], s.status()[0]) and np.array_equal(p.evals()[1], s.evals()[1])
+    assert np.array_equal(p.objective(), s.objective(), equal_nan=True)
+    p.solve(raise_on_error=False)               # once more on the same slots (leftovers of the previous solve)
+    assert np.array_equal(p.objective(), s.objective(), equal_nan=True) and np.array_equal(p.evals()[1], s.evals()[1])
+    p.close()
+    s.close()
+    m2 = examples.deaton2()
+    s2 = gpu_solve(m2)
+    ok, rep = compare(s2.solution(0), Oracle(m2).solve(), rtol=0.0, th_tol=0.0)
+    assert ok, rep
+    s2.close()
+
+
 def test_cycle_of_the_zero_consumption_resend_is_accounted_for_not_executed():
     """C2 on the surveyed credit limit: a draw whose guess stream (it=14, worker) enters a CYCLE of the resend -- the re-sent guess
     signals c1<=0 at another shock node, the guess prepared for that node signals it at the first one again -- which the reference

@@ -167,13 +167,16 @@ def test_plain_sequential_walk_build_agrees():
 
 
 @pytest.mark.skipif(_asan() is None, reason='libasan not found')
-@pytest.mark.parametrize('mode', ['fast', 'defer_all', 'off'])
+@pytest.mark.parametrize('mode', ['fast', 'defer_all', 'defer_late', 'off'])
 def test_single_choice_envelope_kernels(mode):
-    """Single-choice models compact a cell with many workgroups (k_env1_*); irregular cells are handed to k_envelope.
-    The fast path, the hand-over (forced for every cell) and the general kernel alone must all equal the oracle."""
+    """Single-choice models compact a cell with many workgroups (k_env1: tiles with look-back); irregular cells are handed to
+    k_envelope.  The fast path, the hand-over (forced for every cell, before and after the tiles have written rows) and the general
+    kernel alone must all equal the oracle."""
     env = dict(os.environ, LD_PRELOAD=_asan(), ASAN_OPTIONS='detect_leaks=0', EMU_SANITIZE='address')
     if mode == 'defer_all':
         env['EGDST_E1_DEFER_ALL'] = '1'
+    if mode == 'defer_late':   # every cell handed over AFTER its tiles wrote rows into the table: the marks must cover them
+        env['EGDST_E1_DEFER_ALL'] = '2'
     if mode == 'off':
         env['EGDST_NO_ENV1'] = '1'
     r = subprocess.run([sys.executable, os.path.join(HERE, 'cpu_emu', 'run_emu.py'), 'deaton2', ''], env=env,
