@@ -3386,8 +3386,13 @@ struct TpShared {
     int oob, res[3];
 };
 
+// the last kept candidate of every thread of k_tp_prep's one-pass form, for the threads after it
+struct TpPrepShared {
+    int has[TP_BS];
+    double m[TP_BS], c[TP_BS], v[TP_BS];
+};
 // bxi: cell slot of the group * MS_ND + choice
-static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpShared *S)
+static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpShared *S, TpPrepShared *X)
 {
     int *const sh = S->sh, *const s_fstart = S->fstart;
     int &s_oob = S->oob;
@@ -3412,10 +3417,129 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
     double *sM = b.sM + wo, *sC = b.sC + wo, *sV = b.sV + wo;
     int *sF = b.sF + wo;
     const size_t co = eg_cand(b, draw, ist, id);
-    // ---- stop rule: the first requested point whose returned M stops the stream is itself kept (:1100) -----------------------
-    int nreq = 0, fusedstats = 0;
+    int nfold = 0, cnt = 0;
     unsigned long long evals = 0;
     double evfa0 = P.evfa0;
+    const int navail_ = P.seq ? P.np - 1 : (P.grid ? min(ngridm - 1, ngridmax - 1 - P.ncalls) : 0);
+#ifndef TP_PREP_ONEPASS
+#define TP_PREP_ONEPASS 1
+#endif
+    if (TP_PREP_ONEPASS && navail_ + 1 <= ENV_CK * TP_BS) {
+        // ---- ONE pass (round 4): a list of at most ENV_CK * TP_BS candidates is read once, ENV_CK consecutive candidates per
+        // thread, and everything below works on registers: stop rule (:1100), keep rule (:634) with the statistics of the requested
+        // points, fold detection and the pieces of a folded list with their extrapolation points (:776-835).  The earlier form
+        // (kept below for longer lists) read the candidates twice and the compacted list twice more; the numbers and the order of
+        // every write are the same.
+        const int n0 = ENV_CK * tid;
+        double vM[ENV_CK], vC[ENV_CK], vV[ENV_CK];
+        int sc[ENV_CK], keep[ENV_CK];
+#pragma unroll
+        for (int k = 0; k < ENV_CK; k++) {
+            const int n = n0 + k;
+            vM[k] = vC[k] = vV[k] = 0, sc[k] = 0, keep[k] = 0;
+            if (n <= navail_) {
+                vM[k] = b.cM[co + n], vC[k] = b.cC[co + n], vV[k] = b.cV[co + n];
+                if (!P.seq && n >= 1) sc[k] = b.cSt[co + n];
+            }
+        }
+        int nreq = navail_;
+        if (!P.seq) {
+            int first = navail_ + 1;
+#pragma unroll
+            for (int k = ENV_CK - 1; k >= 0; k--)
+                if (n0 + k >= 1 && n0 + k <= navail_ && !(vM[k] < mmax)) first = n0 + k;
+            first = blk_min(first, sh);
+            nreq = min(first, navail_);
+        } else
+            evals = (unsigned long long)P.probe_evals;
+        int hard = 0, n12 = 0, ev = 0, mine = 0;
+        double lm = 0, lc = 0, lv = 0;
+#pragma unroll
+        for (int k = 0; k < ENV_CK; k++) {
+            const int n = n0 + k;
+            if (n > nreq) continue;
+            if (P.seq)
+                keep[k] = 1;
+            else if (n == 0)
+                keep[k] = P.np;
+            else {
+                const int st = eg_sc_status(sc[k]);
+                if (st < 0) hard = max(hard, -st);
+                n12 |= (st == 1) | ((st == 2) << 1);
+                ev += eg_sc_count(sc[k]);
+                keep[k] = (st == 0 && isfinite(vM[k]));
+            }
+            if (keep[k]) mine++, lm = vM[k], lc = vC[k], lv = vV[k];
+        }
+        X->has[tid] = mine, X->m[tid] = lm, X->c[tid] = lc, X->v[tid] = lv;
+        __syncthreads();
+        // the kept point before this thread's first one (nearly always the previous thread's last)
+        int have = 0;
+        double pm = 0, pc = 0, pv = 0;
+        if (mine)
+            for (int t = tid - 1; t >= 0 && !have; t--)
+                if (X->has[t]) pm = X->m[t], pc = X->c[t], pv = X->v[t], have = 1;
+        int fold[ENV_CK], myfolds = 0;
+        double qc[ENV_CK], qv[ENV_CK];  // C and V of the kept point before a fold (its extrapolation point)
+#pragma unroll
+        for (int k = 0; k < ENV_CK; k++) {
+            fold[k] = 0, qc[k] = qv[k] = 0;
+            if (!keep[k]) continue;
+            if (have && (pm > vM[k] || pv > vV[k])) fold[k] = 1, qc[k] = pc, qv[k] = pv, myfolds++;
+            pm = vM[k], pc = vC[k], pv = vV[k], have = 1;
+        }
+        int tot;
+        const int ex = blk_scan_int(mine | (myfolds << 16), sh, &tot);
+        cnt = tot & 0xffff, nfold = (cnt > 1) ? (tot >> 16) : 0;
+        int d = ex & 0xffff;
+        // (a folded list goes on as its pieces in the s slice; its p slice is where the secondary envelope will be written, and
+        //  nothing reads it before that: k_tp_sort stage 0 sorts the pieces, k_envelope works from the candidates)
+#pragma unroll
+        for (int k = 0; k < ENV_CK; k++)
+            if (keep[k]) {
+                if ((size_t)d >= W)
+                    s_oob = 1;
+                else if (nfold == 0)
+                    pM[d] = vM[k], pC[d] = vC[k], pV[d] = vV[k];
+                d++;
+            }
+        if (!P.seq) {
+            blk_reduce3(&hard, &n12, &ev, sh);
+            evals += (unsigned long long)ev + (unsigned long long)P.probe_evals;
+            if (hard || (n12 & 1)) TP_DEFER(3);  // a hard error, a zero-consumption signal left over: k_envelope reports them
+            if (n12 & 2) evfa0 = -INFINITY;
+        }
+        __syncthreads();
+        if (s_oob) TP_DEFER(4);
+        if (nfold > 0) {
+            if (id + nfold + 1 > TP_NF) TP_DEFER(5);
+            int i = ex & 0xffff, sidx = ex >> 16, lastfold = 0;
+#pragma unroll
+            for (int k = 0; k < ENV_CK; k++)
+                if (keep[k]) {
+                    sidx += fold[k];  // pieces closed before this point
+                    const int dd = i + sidx;
+                    if ((size_t)dd >= W)
+                        s_oob = 1;
+                    else {
+                        sM[dd] = vM[k], sC[dd] = vC[k], sV[dd] = vV[k], sF[dd] = id + sidx;
+                        if (fold[k]) {
+                            sM[dd - 1] = 1.5 * mmax, sC[dd - 1] = qc[k], sV[dd - 1] = qv[k], sF[dd - 1] = id + sidx - 1;
+                            s_fstart[id + sidx] = dd;
+                            if (sidx == nfold) lastfold = i;
+                        }
+                    }
+                    if (i == 0) s_fstart[id] = 0;
+                    i++;
+                }
+            lastfold = blk_sum(lastfold, sh);
+            if (s_oob || lastfold + (nfold - 1) >= ngridmax) TP_DEFER(6);  // (:823 not enough space: k_envelope reports it)
+            __syncthreads();
+            for (int f = tid; f < id + nfold + 1; f += TP_BS) R->fstart[f] = (f < id) ? 0 : s_fstart[f];
+        }
+    } else {
+    // ---- stop rule: the first requested point whose returned M stops the stream is itself kept (:1100) -----------------------
+    int nreq = 0, fusedstats = 0;
     if (P.seq) {
         nreq = P.np - 1;  // k_fixup stored the kept points of the whole stream in order
         evals = (unsigned long long)P.probe_evals;
@@ -3429,7 +3553,7 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
         fusedstats = 1;
     }
     // ---- compaction of the kept points (:634) with the statistics of the requested ones -----------------------------------
-    int hard = 0, n12 = 0, ev = 0, cnt = 0;
+    int hard = 0, n12 = 0, ev = 0;
     {
         int carry = 0;
         for (int base = 0; base <= nreq; base += ENV_CK * TP_BS) {
@@ -3481,7 +3605,6 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
     __syncthreads();
     if (s_oob) TP_DEFER(4);
     // ---- does the list fold back?  then it needs a secondary envelope (:776-913) -------------------------------------------
-    int nfold = 0;
     if (cnt > 1) {
         for (int i = 1 + tid; i < cnt; i += TP_BS)
             if (pM[i - 1] > pM[i] || pV[i - 1] > pV[i]) nfold++;
@@ -3519,12 +3642,14 @@ static __device__ __forceinline__ void tp_prep(BatchRef b, int it, int bxi, TpSh
         __syncthreads();
         for (int f = tid; f < id + nfold + 1; f += TP_BS) R->fstart[f] = (f < id) ? 0 : s_fstart[f];
     }
+    }
     if (tid == 0) R->active = 1, R->cnt = cnt, R->nfold = nfold, R->evfa0 = evfa0, R->evals = evals;
 }
 __global__ void __launch_bounds__(TP_BS, TP_PREP_MINW) k_tp_prep(const Batch *bp_, int it)
 {
     __shared__ TpShared S;
-    tp_prep(EG_BATCH_REF(bp_), it, (int)blockIdx.x, &S);
+    __shared__ TpPrepShared X;
+    tp_prep(EG_BATCH_REF(bp_), it, (int)blockIdx.x, &S, &X);
 }
 
 // stage 0: the pieces of one folded choice list (secondary envelope); stage 1: the choice lists of a cell (primary).
