@@ -668,6 +668,13 @@ def main():
             out['speedup_vs_cpu_1thread'] = out['value'] / out['cpu_baseline']['value']
             if out.get('single_solve_ms'):
                 out['single_solve_speedup_vs_cpu'] = out['cpu_baseline']['wall_s_per_solve'] * 1e3 / out['single_solve_ms']
+            if 'c3' in out.get('single_solve_other', {}) and args.workload == 'C2' and not args.small:
+                # BASELINE configs[2] (model_occ3, one solve on one GPU): the oracle's single-thread time for that very solve (~2.6 s)
+                m3 = workloads.c3()[0]
+                ev3, n3, dt3 = _oracle_worker(('C3', {}, [m3.param_vector()], 0.0))
+                c3 = out['single_solve_other']['c3']
+                c3['cpu_ms'], c3['cpu_evals'] = dt3 / max(n3, 1) * 1e3, int(ev3)
+                c3['speedup_vs_cpu_1thread'] = c3['cpu_ms'] / c3['single_solve_ms']
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -5,7 +5,7 @@ import numpy as np
 from egdst_amd import build, runtime, workloads
 os.environ['EGDST_ENV_TP'] = '1'
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-m, gen = workloads.c2(a0=0)
+m, gen = workloads.c2(a0=float(os.environ.get('EGDST_DIAG_A0', '0')))
 lib = build.build_model(m, extra_flags=['-DEGDST_TPSTAMPS'] + sys.argv[2:])
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
 s.set_params(gen(nd))
