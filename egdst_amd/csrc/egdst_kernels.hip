@@ -2115,17 +2115,32 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
     // step two: the sorted stream, position by position (see the head of this function).  `of` may hold the permutation:
     // every position is read and rewritten by the same thread.
     if (!*oob) {
-        for (int r = threadIdx.x; r < npts; r += ENV_BS) {
-            const int i = perm_lds ? (int)lperm[r] : of[r];
-            if (i < 0 || i >= npts) {  // (a rank taken twice leaves a hole: never expected, the walk would read garbage)
-                *oob = 1;
-                continue;
+        // (four positions per thread and round: their gathered loads in flight together, then the stores -- position by position
+        //  the loop was a chain of dependent global reads, a sixth of a sort on the throughput path)
+        for (int r0 = threadIdx.x; r0 < npts; r0 += 4 * ENV_BS) {
+            double gm[4], gc[4], gv[4];
+            int gf[4], gi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u * ENV_BS;
+                gi[u] = -2, gm[u] = gc[u] = gv[u] = 0, gf[u] = 0;
+                if (r < npts) {
+                    const int i = perm_lds ? (int)lperm[r] : of[r];
+                    gi[u] = (i < 0 || i >= npts) ? -1 : i;  // (a rank taken twice leaves a hole: never expected, the walk would read garbage)
+                    if (gi[u] >= 0) gm[u] = im[i], gc[u] = ic[i], gv[u] = iv[i], gf[u] = ifn[i];
+                }
             }
-            om[r] = im[i];
-            oc[r] = ic[i];
-            ov[r] = iv[i];
-            of[r] = ifn[i];
-            if (perm_lds && cls && *fused) cls[r] = lcls[r];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u * ENV_BS;
+                if (gi[u] == -1) *oob = 1;
+                if (gi[u] < 0) continue;
+                om[r] = gm[u];
+                oc[r] = gc[u];
+                ov[r] = gv[u];
+                of[r] = gf[u];
+                if (perm_lds && cls && *fused) cls[r] = lcls[r];
+            }
         }
     }
     __syncthreads();
@@ -2693,13 +2708,26 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             // every thread finds the segment of its output row from the running totals)
             int off = 0, offj = 0;
             for (int k = 0; k < nseg; k++) off += sg_oi[k], offj += sg_oj[k];
-            for (int r = tid_; r < off; r += ENV_BS) {
-                int k = 0, q = r;
-                while (q >= sg_oi[k]) q -= sg_oi[k], k++;
-                const size_t src = 2 * (size_t)sg_p[k] + 64 * (size_t)k + q;
-                j.og[r] = j.wM[src];
-                j.ov[r] = j.wV[src];
-                j.oc[r] = j.wC[src];
+            // (four rows per thread and round: all their loads in flight, then the stores -- a row at a time the loop was a chain
+            //  of global round trips, 8 us of a 37-us walk on the throughput path, profiles/r04_stamps_seg2_tp.txt)
+            for (int r0 = tid_; r0 < off; r0 += 4 * ENV_BS) {
+                double gm[4], gv[4], gc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = r0 + u * ENV_BS;
+                    gm[u] = gv[u] = gc[u] = 0;
+                    if (r < off) {
+                        int k = 0, q = r;
+                        while (q >= sg_oi[k]) q -= sg_oi[k], k++;
+                        const size_t src = 2 * (size_t)sg_p[k] + 64 * (size_t)k + q;
+                        gm[u] = j.wM[src], gv[u] = j.wV[src], gc[u] = j.wC[src];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = r0 + u * ENV_BS;
+                    if (r < off) j.og[r] = gm[u], j.ov[r] = gv[u], j.oc[r] = gc[u];
+                }
             }
             for (int r = tid_; r < offj; r += ENV_BS) {
                 int k = 0, q = r;
@@ -2711,11 +2739,24 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             if (ENV_CDEFER(L)) {  // the consumption of the rows the batches kept (env_walk_wave), over the gathered rows
                 __syncthreads();
                 int k = 0, offk = 0;
-                for (int p = tid_; p < j.npts; p += ENV_BS) {
-                    while (p >= sg_p[k + 1]) offk += sg_oi[k], k++;
-                    if (p >= sg_end[k]) continue;
-                    const int d = cls[p];
-                    if (d >= 0) j.oc[offk + d] = c[p];
+                for (int p0 = tid_; p0 < j.npts; p0 += 4 * ENV_BS) {  // (four positions per thread and round, as above)
+                    int dst[4];
+                    double cc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int p = p0 + u * ENV_BS;
+                        dst[u] = -1, cc[u] = 0;
+                        if (p < j.npts) {
+                            while (p >= sg_p[k + 1]) offk += sg_oi[k], k++;
+                            if (p < sg_end[k]) {
+                                const int d = cls[p];
+                                if (d >= 0) dst[u] = offk + d, cc[u] = c[p];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (dst[u] >= 0) j.oc[dst[u]] = cc[u];
                 }
             }
             if (tid_ < WAVE) *err = 0, *n = off, *nth = offj;
@@ -2740,9 +2781,21 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
     if (ENV_CDEFER(L)) {  // the consumption of the rows the batches kept (env_walk_wave)
         __syncthreads();
         const int pe = sg_end[0];
-        for (int p = tid_; p < pe; p += ENV_BS) {
-            const int d = cls[p];
-            if (d >= 0) j.oc[d] = c[p];
+        for (int p0 = tid_; p0 < pe; p0 += 4 * ENV_BS) {
+            int dst[4];
+            double cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p0 + u * ENV_BS;
+                dst[u] = -1, cc[u] = 0;
+                if (p < pe) {
+                    const int d = cls[p];
+                    if (d >= 0) dst[u] = d, cc[u] = c[p];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (dst[u] >= 0) j.oc[dst[u]] = cc[u];
         }
     }
 #ifdef EGDST_STAMPS2

@@ -503,6 +503,9 @@ class Solver:
             tm = torch.zeros(self.ndraw, self.nt, nout, dtype=torch.float64, device='cuda')
             tc = torch.zeros(self.ndraw, self.nt, nout, dtype=torch.int32, device='cuda')
             to = torch.zeros(self.ndraw, dtype=torch.float64, device='cuda')
+            # torch fills them on ITS stream; the library writes them on the handle's: without this the fill may land after the
+            # results (seen once in a few hundred runs: all moments and objectives zero)
+            torch.cuda.current_stream().synchronize()
             means_dev, counts_dev, obj_dev = tm.data_ptr(), tc.data_ptr(), to.data_ptr()
         self.lib.check(self.lib.lib.egdst_simulate_batch_moments(
             self.h, _dp(init), init.shape[0], C.c_void_p(randstream_dev) if randstream_dev else None, int(nrand), int(seed),
