@@ -2077,6 +2077,16 @@ static __device__ __forceinline__ void blk_rank_sort(int npts, int nf, const dou
         else
             eg_rank_classify_run(i0, n, nf, im, iv, f, m, v, fstart, dims, cls != nullptr, kbound, ana, r, w,
                                  (const eg_ldsd *)lkeys, sk);
+#ifdef EGDST_RANKCHK  // diagnostic build: every rank against a plain count (as in blk_sort_lds)
+        for (int k = 0; k < n; k++) {
+            const int i = i0 + k;
+            int rc_ = 0;
+            for (int j = 0; j < npts; j++)
+                if (pt_before(im[j], iv[j], ifn[j], j, im[i], iv[i], ifn[i], i)) rc_++;
+            if (dbg) atomicAdd(&dbg[12], 1);
+            if (rc_ != r[k] && dbg) atomicAdd(&dbg[13], 1);
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < ENV_RK; k++) {
             if (k >= n) continue;

@@ -85,8 +85,11 @@ WORKLOADS = {'C1': c1, 'C2': c2, 'C3': c3, 'C4': c4, 'C5': c5}
 #    launch: 169.8 ms against 167.1 for C2 a0=-5 x 4096 -- the scan launch costs nothing a chain notices; not kept.)
 #  * C5, round 4: -DGRID_BS=1024 as well (with the branch-free searches the longer staging of a larger index is shared by four times the
 #    points: C5 x 128 3.28 -> 3.22 s; 512 points per workgroup: 3.36 s).
+#  * C5, round 4: -DENV_RK=4: a thread of the global-memory sort ranks four consecutive points, the later ones galloping on from their
+#    predecessor's count (one or two dependent global reads instead of five; on C2's LDS-resident keys the same lost): C5 x 128
+#    3.17 -> 3.12-3.14 s (2: 3.15, 8: 3.15, 16: 3.27).
 #  * C2, round 4: -DENV_SEG_MINPTS=128 (default 192, tuned for k_envelope's eight walking waves): a stage-0 stream of the throughput
 #    path (~1050 points) is cut into eight segments for its four walking waves instead of five; C2 a0=-5 x 4096 159.8 -> 157.3 ms per
 #    solve (112 ... 160: 156.5 ... 157.7; a0=0 unchanged; the event cost of the planner 160 ... 1280: no difference).
-BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3', '-DGRID_BS=512', '-DEG_GRID_CV_DEFAULT=1', '-DGRID_MINW=8', '-DENV_SEG_MINPTS=128'], 'C4': ['-DGRID_MINW=8', '-DGRID_BS=1024'], 'C5': ['-DGRID_MINW=8', '-DGRID_BS=1024']}
+BATCH_BUILD_FLAGS = {'C2': ['-DENV_MINW=3', '-DGRID_BS=512', '-DEG_GRID_CV_DEFAULT=1', '-DGRID_MINW=8', '-DENV_SEG_MINPTS=128'], 'C4': ['-DGRID_MINW=8', '-DGRID_BS=1024'], 'C5': ['-DGRID_MINW=8', '-DGRID_BS=1024', '-DENV_RK=4']}
 BATCH_BUILD_MIN_DRAWS = {'C2': 1024, 'C4': 16, 'C5': 64}

@@ -3,9 +3,13 @@ import os, sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from egdst_amd import build, runtime, workloads
-os.environ['EGDST_ENV_TP'] = '1'
 nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-m, gen = workloads.c2(a0=float(os.environ.get('EGDST_DIAG_A0', '0')))
+wl = os.environ.get('EGDST_DIAG_WL', 'C2')   # (C5, C3: the same stamps inside k_envelope's global-memory sorts)
+if wl == 'C2':
+    os.environ['EGDST_ENV_TP'] = '1'
+    m, gen = workloads.c2(a0=float(os.environ.get('EGDST_DIAG_A0', '0')))
+else:
+    m, gen = workloads.WORKLOADS[wl]()
 lib = build.build_model(m, extra_flags=['-DEGDST_TPSTAMPS'] + sys.argv[2:])
 s = runtime.Solver(lib, m.descriptor(), ndraw=nd, keep_history=False)
 s.set_params(gen(nd))

@@ -796,20 +796,25 @@ def test_segmented_envelope_walks_are_used_and_exact(monkeypatch):
 # the build variants the tests of this file load besides the default libraries: (model factory, extra hipcc flags).
 # __graft_entry__.build() compiles them in-tree beforehand, so that the GPU lease never runs hipcc.
 BUILD_VARIANTS = [(lambda: TP_CASES['C2'](), ['-DEGDST_RANKCHK']), (lambda: TP_CASES['occ3_n400'](), ['-DEGDST_RANKCHK']),
+                  (lambda: TP_CASES['occ3_n400'](), ['-DEGDST_RANKCHK', '-DENV_RK=4']),
                   (lambda: workloads.c2(a0=0, ngridm=300, T=30)[0], ['-DENV_LANE_STEP=0', '-DENV_CDEFER_ON=0'])]
 
 
-@pytest.mark.parametrize('name,tp', [('C2', '0'), ('occ3_n400', '1'), ('occ3_n400', '0')])
-def test_every_rank_of_the_sort_equals_a_plain_count(name, tp, monkeypatch):
+@pytest.mark.parametrize('name,tp,rk', [('C2', '0', 1), ('occ3_n400', '1', 1), ('occ3_n400', '0', 1), ('occ3_n400', '0', 4)])
+def test_every_rank_of_the_sort_equals_a_plain_count(name, tp, rk, monkeypatch):
     """The checking build of the sort (-DEGDST_RANKCHK): every rank that the rank-merge of the envelope step assigns from
     binary searches (eg_rank_classify_run: comp1 order of egdst_solver.c:1570-1582 extended by the input index) is compared on
     the device with a plain count over the whole stream -- C2 at full size through k_envelope (the secondary envelopes of
     lists with several folds), a three-choice model through the throughput path and through k_envelope: thousands of ranks
     checked, none differs, and the solution is still the oracle's.  (Two-list merges take the merge path, which assigns
-    positions, not ranks.)"""
+    positions, not ranks.)  rk = 4: the C5 batch build's form (-DENV_RK=4: a thread ranks four consecutive points, the later ones
+    galloping on from their predecessor's count) with an LDS budget so small that the keys are a sampled index and the searches end
+    in global memory, as on C5's 65 536-point streams."""
     monkeypatch.setenv('EGDST_ENV_TP', tp)
+    if rk > 1:
+        monkeypatch.setenv('EGDST_LCAP', '200')
     m = TP_CASES[name]()
-    lib = build.build_model(m, extra_flags=['-DEGDST_RANKCHK'])
+    lib = build.build_model(m, extra_flags=['-DEGDST_RANKCHK'] + (['-DENV_RK=%d' % rk] if rk > 1 else []))
     s = runtime.Solver(lib, m.descriptor(), ndraw=1, keep_history=True)
     s.set_params(m.param_vector()[None])
     assert s.solve(raise_on_error=False) == 0
