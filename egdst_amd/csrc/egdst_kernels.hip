@@ -2616,9 +2616,13 @@ static __device__ __forceinline__ void run_walk(const ms_env *E, const WalkJob &
             total += sg_w[w];
         }
         incl += before;
-        for (int k = 1; k < nseg; k++) {  // the chunk in which the running cost passes k/nseg of the total
-            const long long thr = (long long)total * k / nseg;
-            if (incl - cost < thr && thr <= incl) sg_p[k] = min(tid_ * C, j.npts - 1);
+        {   // the chunk in which the running cost passes k/nseg of the total (thresholds k * floor(total / nseg): where exactly a
+            // cut falls is a matter of balance only, and one 32-bit division replaces seven 64-bit ones per thread)
+            const int per = total / nseg;
+            for (int k = 1; k < nseg; k++) {
+                const int thr = per * k;
+                if (incl - cost < thr && thr <= incl) sg_p[k] = min(tid_ * C, j.npts - 1);
+            }
         }
         if (tid_ < nseg && total <= 0) sg_p[tid_] = -1;
         __syncthreads();
